@@ -1,0 +1,83 @@
+"""ctypes binding of libltxk.so (include/ltxk.h).  Fails loudly when the HIP extension is
+missing: there is no CPU fallback on the product path."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libltxk.so")
+
+
+class LtxkError(RuntimeError):
+    pass
+
+
+class GemmArgs(Structure):
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+        ("resid", c_void_p), ("gate", c_void_p), ("gate_row", c_void_p),
+        ("M", c_int32), ("N", c_int32), ("K", c_int32),
+        ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32), ("gate_stride", c_int32),
+        ("epilogue", c_int32), ("out_tokens_per_batch", c_int32),
+    ]
+
+
+class Conv3dArgs(Structure):
+    _fields_ = [
+        ("x", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+        ("resid", c_void_p), ("zero_page", c_void_p),
+        ("B", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
+        ("Cin", c_int32), ("Cout", c_int32),
+        ("causal", c_int32), ("pad_mode", c_int32), ("d2s", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/ltxk.h one to one.
+SIGNATURES = {
+    "ltxk_version": (c_int32, []),
+    "ltxk_last_error": (c_char_p, []),
+    "ltxk_gemm_bf16": (c_int32, [POINTER(GemmArgs), c_void_p]),
+    "ltxk_flash_attn_bf16": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                       c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    "ltxk_rmsnorm_modulate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
+                                        c_void_p, c_void_p]),
+    "ltxk_layernorm_modulate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
+                                          c_void_p, c_void_p]),
+    "ltxk_qknorm_rope": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_int32, c_int32, c_float, c_void_p]),
+    "ltxk_timestep_embed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ltxk_ada_combine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ltxk_latent_to_tokens": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_cfg_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                      c_int32, c_float, c_float, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libltxk.so; raise LtxkError with the build recipe if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LtxkError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C mlx-video_amd/csrc`). "
+            "There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ltxk_last_error()
+        raise LtxkError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,54 @@
+// Shared device/host helpers for libltxk (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/ltxk.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LTXK_WAVE 64
+
+// Thread-local error string (never throws across the ABI).
+void ltxk_set_error(const char* fmt, ...);
+
+#define LTXK_CHECK_ARG(cond, ...)                  \
+  do {                                             \
+    if (!(cond)) {                                 \
+      ltxk_set_error(__VA_ARGS__);                 \
+      return LTXK_EINVAL;                          \
+    }                                              \
+  } while (0)
+
+#define LTXK_CHECK_LAUNCH(name)                                                  \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      ltxk_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return LTXK_ELAUNCH;                                                       \
+    }                                                                            \
+  } while (0)
+
+// Round fp32 to bf16 storage and back: the "materialise a bf16 array" point of the reference.
+__device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // nn.gelu_approx: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  // tanh(u) = 1 - 2/(exp(2u)+1)
+  const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}

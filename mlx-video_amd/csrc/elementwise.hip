@@ -1,0 +1,338 @@
+// HBM-bound row / elementwise kernels of the DiT step (include/ltxk.h).  All loads/stores are
+// 8- or 16-byte vectors; row reductions are wave64 shuffles (one wave per row); every bf16
+// rounding point of the reference's op chain is reproduced.
+#include "common.h"
+#include <math.h>
+
+namespace ltxk {
+
+constexpr int ROWS_PER_BLOCK = 4;  // one wave per row, 4 waves per workgroup
+constexpr int MAX_CHUNKS = 16;     // D <= 16*512 = 8192
+
+// ---------------------------------------------------------------------------------------
+// rms_norm / layer_norm (no affine) + AdaLN modulation
+// ---------------------------------------------------------------------------------------
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void norm_modulate_kernel(
+    const bf16* __restrict__ x, bf16* __restrict__ y, int M, int D, float eps,
+    const bf16* __restrict__ scale, const bf16* __restrict__ shift, int mod_stride,
+    const int32_t* __restrict__ mod_row) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16* xr = x + (size_t)row * D;
+  const int nch = D >> 9;  // chunks of 512 elements (64 lanes x 8)
+  bf16x8 v[MAX_CHUNKS];
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAX_CHUNKS; ++i) {
+    if (i < nch) {
+      v[i] = *(const bf16x8*)(xr + i * 512 + lane * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[i][j];
+        sum += f;
+        sq += f * f;
+      }
+    }
+  }
+  float mean = 0.f, rstd;
+  if constexpr (LAYERNORM) {
+    mean = wave_sum(sum) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_CHUNKS; ++i)
+      if (i < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = (float)v[i][j] - mean;
+          var += d * d;
+        }
+      }
+    var = wave_sum(var) / (float)D;
+    rstd = rsqrtf(var + eps);
+  } else {
+    rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  }
+  const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
+  bf16* yr = y + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAX_CHUNKS; ++i) {
+    if (i < nch) {
+      const int col = i * 512 + lane * 8;
+      bf16x8 o;
+      if (scale) {
+        const bf16x8 sc = *(const bf16x8*)(scale + mrow + col);
+        const bf16x8 sh = *(const bf16x8*)(shift + mrow + col);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float n = rbf(((float)v[i][j] - mean) * rstd);
+          const float one_p = rbf(1.0f + (float)sc[j]);
+          o[j] = (bf16)(rbf(n * one_p) + (float)sh[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)v[i][j] - mean) * rstd);
+      }
+      *(bf16x8*)(yr + col) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// q/k RMSNorm (full inner dim, learned weight) + SPLIT RoPE, in place.
+// Lane map: a wave pass covers 4 heads; 16 lanes per head; lane handles x1 = [j0,j0+4) of the
+// first half and x2 = the same offsets of the second half (the rotation partners).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(
+    bf16* __restrict__ buf, int ld, int M, int nseg, int D, const bf16* __restrict__ weight,
+    const float* __restrict__ cosb, const float* __restrict__ sinb, int T, int H, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int t = row % T;
+  const int npass = H >> 2;          // 4 heads per pass (H % 4 == 0), dh = 128
+  const int hl = lane >> 4;          // head within pass
+  const int j0 = (lane & 15) * 4;    // offset within the 64-wide half
+  constexpr int MAXP = 8;            // H <= 32
+  f32x4 cs[MAXP], sn[MAXP];
+  if (cosb) {
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps)
+      if (ps < npass) {
+        const size_t off = ((size_t)(ps * 4 + hl) * T + t) * 64 + j0;
+        cs[ps] = *(const f32x4*)(cosb + off);
+        sn[ps] = *(const f32x4*)(sinb + off);
+      }
+  }
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    bf16* xr = buf + (size_t)row * ld + (size_t)sgi * D;
+    const bf16* wr = weight + (size_t)sgi * D;
+    bf16x4 a[MAXP], b[MAXP];
+    float sq = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps)
+      if (ps < npass) {
+        const int base = (ps * 4 + hl) * 128 + j0;
+        a[ps] = *(const bf16x4*)(xr + base);
+        b[ps] = *(const bf16x4*)(xr + base + 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float fa = (float)a[ps][j], fb = (float)b[ps][j];
+          sq += fa * fa + fb * fb;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int ps = 0; ps < MAXP; ++ps)
+      if (ps < npass) {
+        const int base = (ps * 4 + hl) * 128 + j0;
+        const bf16x4 wa = *(const bf16x4*)(wr + base);
+        const bf16x4 wb = *(const bf16x4*)(wr + base + 64);
+        bf16x4 oa, ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x1 = rbf((float)a[ps][j] * rstd * (float)wa[j]);
+          const float x2 = rbf((float)b[ps][j] * rstd * (float)wb[j]);
+          if (cosb) {
+            const float c = cs[ps][j], s = sn[ps][j];
+            oa[j] = (bf16)(x1 * c - s * x2);
+            ob[j] = (bf16)(x2 * c + s * x1);
+          } else {
+            oa[j] = (bf16)x1;
+            ob[j] = (bf16)x2;
+          }
+        }
+        *(bf16x4*)(xr + base) = oa;
+        *(bf16x4*)(xr + base + 64) = ob;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------
+__global__ void timestep_embed_kernel(const bf16* __restrict__ t, bf16* __restrict__ out, int U, int dim) {
+  const int half = dim >> 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= U * half) return;
+  const int u = idx / half, i = idx - u * half;
+  const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // -ln(1e4)
+  const float arg = (float)t[u] * freq;
+  out[(size_t)u * dim + i] = (bf16)cosf(arg);          // flip_sin_to_cos: cos first
+  out[(size_t)u * dim + half + i] = (bf16)sinf(arg);
+}
+
+__global__ void ada_combine_kernel(const bf16* __restrict__ table, const bf16* __restrict__ ada,
+                                   bf16* __restrict__ out, int L, int U, int K, int D) {
+  // out[l,u,k,d] = bf16(table[l,k,d] + ada[u,k,d]); 8 elements per thread
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t kd8 = (size_t)K * D / 8;
+  const size_t total = (size_t)L * U * kd8;
+  if (idx >= total) return;
+  const size_t e = idx % kd8;
+  const size_t lu = idx / kd8;
+  const int u = (int)(lu % U), l = (int)(lu / U);
+  const bf16x8 a = *(const bf16x8*)(table + ((size_t)l * kd8 + e) * 8);
+  const bf16x8 b = *(const bf16x8*)(ada + ((size_t)u * kd8 + e) * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] + (float)b[j]);
+  *(bf16x8*)(out + idx * 8) = o;
+}
+
+__global__ void silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n8) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const bf16x8 v = *(const bf16x8*)(x + idx * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float f = (float)v[j];
+    o[j] = (bf16)(f / (1.0f + expf(-f)));
+  }
+  *(bf16x8*)(y + idx * 8) = o;
+}
+
+// (B,C,S) -> (rep*B,S,C): thread = (b, s, 8-channel group); lanes run along s (coalesced reads).
+__global__ void latent_to_tokens_kernel(const bf16* __restrict__ lat, bf16* __restrict__ tok,
+                                        int B, int C, int S, int rep) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = blockIdx.y, b = blockIdx.z;
+  if (s >= S) return;
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = lat[((size_t)b * C + cg * 8 + j) * S + s];
+  for (int r = 0; r < rep; ++r)
+    *(bf16x8*)(tok + (((size_t)(r * B + b)) * S + s) * C + cg * 8) = v;
+}
+
+__global__ void cfg_euler_kernel(const bf16* __restrict__ vp, const bf16* __restrict__ vn,
+                                 const bf16* __restrict__ lat, bf16* __restrict__ out,
+                                 const bf16* __restrict__ clean, const float* __restrict__ mask,
+                                 int B, int C, int S, float cfg, float sigma, float sigma_next) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cg = blockIdx.y, b = blockIdx.z;
+  if (s >= S) return;
+  const size_t tokoff = ((size_t)b * S + s) * C + cg * 8;
+  const bf16x8 p = *(const bf16x8*)(vp + tokoff);
+  bf16x8 n = p;
+  if (vn) n = *(const bf16x8*)(vn + tokoff);
+  float m = 1.f;
+  if (mask) m = mask[(size_t)b * S + s];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const size_t li = ((size_t)b * C + cg * 8 + j) * S + s;
+    float v = (float)p[j];
+    if (vn) v = rbf(v + rbf((cfg - 1.0f) * rbf(v - (float)n[j])));
+    const float x = (float)lat[li];
+    float x0 = rbf(x - sigma * v);
+    if (mask) x0 = rbf(rbf(x0 * m) + rbf((float)clean[li] * rbf(1.0f - m)));
+    float o = x0;
+    if (sigma_next > 0.f) {
+      const float t1 = x - x0;
+      const float t2 = sigma_next * t1;
+      o = x0 + __fdiv_rn(t2, sigma);
+    }
+    out[li] = (bf16)o;
+  }
+}
+
+}  // namespace ltxk
+
+using namespace ltxk;
+
+static int norm_modulate_launch(bool ln, const void* x, void* y, int32_t M, int32_t D, float eps,
+                                const void* scale, const void* shift, int32_t mod_stride,
+                                const int32_t* mod_row, void* stream, const char* name) {
+  LTXK_CHECK_ARG(x && y && M > 0, "%s: null/empty input", name);
+  LTXK_CHECK_ARG(D % 512 == 0 && D <= 512 * MAX_CHUNKS, "%s: D=%d must be a multiple of 512, <= %d", name, D, 512 * MAX_CHUNKS);
+  LTXK_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift must both be set or both NULL", name);
+  LTXK_CHECK_ARG(!scale || mod_stride % 8 == 0, "%s: mod_stride must be a multiple of 8", name);
+  const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  if (ln)
+    hipLaunchKernelGGL(norm_modulate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, M, D, eps,
+                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row);
+  else
+    hipLaunchKernelGGL(norm_modulate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, M, D, eps,
+                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row);
+  LTXK_CHECK_LAUNCH(name);
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_rmsnorm_modulate(const void* x, void* y, int32_t M, int32_t D, float eps,
+                                     const void* scale, const void* shift, int32_t mod_stride,
+                                     const int32_t* mod_row, void* stream) {
+  return norm_modulate_launch(false, x, y, M, D, eps, scale, shift, mod_stride, mod_row, stream, "ltxk_rmsnorm_modulate");
+}
+
+extern "C" int ltxk_layernorm_modulate(const void* x, void* y, int32_t M, int32_t D, float eps,
+                                       const void* scale, const void* shift, int32_t mod_stride,
+                                       const int32_t* mod_row, void* stream) {
+  return norm_modulate_launch(true, x, y, M, D, eps, scale, shift, mod_stride, mod_row, stream, "ltxk_layernorm_modulate");
+}
+
+extern "C" int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
+                                const void* weight, const float* cos, const float* sin,
+                                int32_t T, int32_t H, float eps, void* stream) {
+  LTXK_CHECK_ARG(buf && weight && M > 0 && nseg > 0, "ltxk_qknorm_rope: null/empty input");
+  LTXK_CHECK_ARG(D == H * 128 && H % 4 == 0 && H <= 32, "ltxk_qknorm_rope: need D == H*128, H %% 4 == 0, H <= 32 (D=%d H=%d)", D, H);
+  LTXK_CHECK_ARG(ld >= nseg * D && ld % 4 == 0, "ltxk_qknorm_rope: ld=%d too small", ld);
+  LTXK_CHECK_ARG((cos == nullptr) == (sin == nullptr), "ltxk_qknorm_rope: cos and sin must both be set or both NULL");
+  LTXK_CHECK_ARG(T > 0, "ltxk_qknorm_rope: T must be > 0");
+  const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)buf, ld, M, nseg, D,
+                     (const bf16*)weight, cos, sin, T, H, eps);
+  LTXK_CHECK_LAUNCH("ltxk_qknorm_rope");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t dim, void* stream) {
+  LTXK_CHECK_ARG(t && out && U > 0 && dim > 0 && dim % 2 == 0, "ltxk_timestep_embed: bad arguments");
+  const int total = U * (dim / 2);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)t, (bf16*)out, U, dim);
+  LTXK_CHECK_LAUNCH("ltxk_timestep_embed");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_ada_combine(const void* table, const void* ada, void* out, int32_t L, int32_t U,
+                                int32_t K, int32_t D, void* stream) {
+  LTXK_CHECK_ARG(table && ada && out && L > 0 && U > 0 && K > 0 && D > 0 && D % 8 == 0, "ltxk_ada_combine: bad arguments");
+  const size_t total = (size_t)L * U * K * D / 8;
+  hipLaunchKernelGGL(ada_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)table, (const bf16*)ada, (bf16*)out, L, U, K, D);
+  LTXK_CHECK_LAUNCH("ltxk_ada_combine");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_silu(const void* x, void* y, int64_t n, void* stream) {
+  LTXK_CHECK_ARG(x && y && n > 0 && n % 8 == 0, "ltxk_silu: n must be a positive multiple of 8");
+  const int64_t n8 = n / 8;
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, (bf16*)y, n8);
+  LTXK_CHECK_LAUNCH("ltxk_silu");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_latent_to_tokens(const void* latent, void* tokens, int32_t B, int32_t C, int32_t S,
+                                     int32_t rep, void* stream) {
+  LTXK_CHECK_ARG(latent && tokens && B > 0 && S > 0 && C > 0 && C % 8 == 0 && rep >= 1, "ltxk_latent_to_tokens: bad arguments");
+  hipLaunchKernelGGL(latent_to_tokens_kernel, dim3((S + 63) / 64, C / 8, B), dim3(64), 0, (hipStream_t)stream,
+                     (const bf16*)latent, (bf16*)tokens, B, C, S, rep);
+  LTXK_CHECK_LAUNCH("ltxk_latent_to_tokens");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent, void* out,
+                                   const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
+                                   float cfg_scale, float sigma, float sigma_next, void* stream) {
+  LTXK_CHECK_ARG(v_pos && latent && out && B > 0 && S > 0 && C > 0 && C % 8 == 0, "ltxk_cfg_euler_step: bad arguments");
+  LTXK_CHECK_ARG((clean == nullptr) == (mask == nullptr), "ltxk_cfg_euler_step: clean and mask must both be set or both NULL");
+  LTXK_CHECK_ARG(sigma > 0.f, "ltxk_cfg_euler_step: sigma must be > 0");
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((S + 63) / 64, C / 8, B), dim3(64), 0, (hipStream_t)stream,
+                     (const bf16*)v_pos, (const bf16*)v_neg, (const bf16*)latent, (bf16*)out, (const bf16*)clean, mask,
+                     B, C, S, cfg_scale, sigma, sigma_next);
+  LTXK_CHECK_LAUNCH("ltxk_cfg_euler_step");
+  return LTXK_OK;
+}

@@ -1,0 +1,261 @@
+// Dense bf16 GEMM with fused epilogues: ltxk_gemm_bf16 (include/ltxk.h).
+// Replaces nn.Linear at attention.py:123-126,142; feed_forward.py:35-40; adaln.py:46,134-138;
+// text_projection.py:22-25; ltx.py:130,455 — and the residual/gate algebra of
+// transformer.py:254,257,347 as epilogues.
+#include "gemm_core.h"
+
+namespace ltxk {
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* W;
+  const bf16* bias;
+  bf16* out;
+  const bf16* resid;
+  const bf16* gate;
+  const int32_t* gate_row;
+  int M, N, K, lda, ldo, ldr, gate_stride;
+  int RT, CT;
+  int T;  // tokens per batch for the transposed output
+};
+
+template <int TT, int EPI, bool TRANS>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
+  using G = GemmGeom<TT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int rt, ct;
+  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
+  const int m0 = rt * G::BM, n0 = ct * GEMM_BN;
+
+  // ---- loader: per-lane source pointers (row clamped, 16-byte chunk pre-swizzled) ----
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const bf16* wptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = n0 + (wave * 4 + i) * 8 + lrow;
+    r = r < p.N ? r : p.N - 1;
+    wptr[i] = p.W + (size_t)r * p.K + chunk * 8;
+  }
+  const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
+  const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
+  const bf16* aptr[G::MAXA];
+#pragma unroll
+  for (int i = 0; i < G::MAXA; ++i) {
+    int r = m0 + (a0 + i) * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + chunk * 8;
+  }
+  const int per_stage = 4 + nA;
+
+  auto issue = [&](int kt, int s) {
+    char* base = smem + s * G::STAGE_BYTES;
+    const int ko = kt * GEMM_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(wptr[i] + ko, base + (wave * 4 + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < G::MAXA; ++i)
+      if (i < nA) glds16(aptr[i] + ko, base + GEMM_W_STAGE_BYTES + (a0 + i) * 1024);
+  };
+
+  f32x4 acc[TT][4];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GEMM_BK;
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int s = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_stage_and_barrier(kt + 1 < nk ? per_stage : 0);
+    if (kt + 2 < nk) {
+      int s2 = s + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      issue(kt + 2, s2);
+    }
+    mma_stage<TT, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
+    s = s + 1 == 3 ? 0 : s + 1;
+  }
+
+  // ---- epilogue ----
+  if constexpr (!TRANS) {
+    // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      int grow = 0;
+      if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) grow = p.gate_row ? p.gate_row[m] : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + nq;
+        if (n >= p.N) continue;
+        float y[4];
+        if (p.bias) {
+          const bf16x4 b = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j]);
+        }
+        if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) {
+          const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)grow * p.gate_stride + n);
+          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_RES) {
+          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+        *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+      }
+    }
+  } else {
+    // acc[tt][nt][j]: n = lane&15, token = 4*(lane>>4) + j ; out[(b*N + n)*ldo + t]
+    const int tq = (lane >> 4) * 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+      if (n >= p.N) continue;
+      const float b = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int m = m0 + wm * TT * 16 + tt * 16 + tq;
+        if (m >= p.M) continue;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[tt][nt][j] + b);
+        const int bidx = m / p.T, t = m - bidx * p.T;
+        bf16* dst = p.out + ((size_t)bidx * p.N + n) * p.ldo + t;
+        if ((p.T & 3) == 0 && m + 3 < p.M) {
+          *(bf16x4*)dst = o;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int mj = m + j;
+            if (mj < p.M) {
+              const int bj = mj / p.T, tj = mj - bj * p.T;
+              p.out[((size_t)bj * p.N + n) * p.ldo + tj] = o[j];
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int TT, int EPI, bool TRANS>
+static int launch(const GemmParams& p, hipStream_t stream) {
+  using G = GemmGeom<TT>;
+  auto kern = gemm_bf16_kernel<TT, EPI, TRANS>;
+  static thread_local bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_BYTES);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
+  LTXK_CHECK_LAUNCH("ltxk_gemm_bf16");
+  return LTXK_OK;
+}
+
+template <int TT>
+static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t stream) {
+  if (trans) return launch<TT, LTXK_EPI_BIAS, true>(p, stream);
+  switch (epi) {
+    case LTXK_EPI_BIAS: return launch<TT, LTXK_EPI_BIAS, false>(p, stream);
+    case LTXK_EPI_BIAS_GELU: return launch<TT, LTXK_EPI_BIAS_GELU, false>(p, stream);
+    case LTXK_EPI_BIAS_SILU: return launch<TT, LTXK_EPI_BIAS_SILU, false>(p, stream);
+    case LTXK_EPI_BIAS_GATE_RES: return launch<TT, LTXK_EPI_BIAS_GATE_RES, false>(p, stream);
+    case LTXK_EPI_BIAS_RES: return launch<TT, LTXK_EPI_BIAS_RES, false>(p, stream);
+  }
+  ltxk_set_error("ltxk_gemm_bf16: unknown epilogue %d", epi);
+  return LTXK_EINVAL;
+}
+
+// Row-tile height: minimise (rounds over 256 CUs) x (tile rows + fixed per-tile overhead).
+static int pick_tt(int M, int N) {
+  const int cand[4] = {5, 4, 2, 1};
+  const int CT = (N + GEMM_BN - 1) / GEMM_BN;
+  int best = 5;
+  long best_cost = -1;
+  for (int i = 0; i < 4; ++i) {
+    const int bm = 32 * cand[i];
+    const long RT = (M + bm - 1) / bm;
+    const long rounds = (RT * CT + 255) / 256;
+    const long cost = rounds * (bm + 48);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = cand[i];
+    }
+  }
+  return best;
+}
+
+}  // namespace ltxk
+
+extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
+  using namespace ltxk;
+  LTXK_CHECK_ARG(a != nullptr, "ltxk_gemm_bf16: null args");
+  LTXK_CHECK_ARG(a->A && a->W && a->out, "ltxk_gemm_bf16: null A/W/out");
+  LTXK_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "ltxk_gemm_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
+  LTXK_CHECK_ARG(a->K % GEMM_BK == 0, "ltxk_gemm_bf16: K=%d must be a multiple of %d", a->K, GEMM_BK);
+  LTXK_CHECK_ARG(a->N % 8 == 0, "ltxk_gemm_bf16: N=%d must be a multiple of 8", a->N);
+  LTXK_CHECK_ARG(a->lda >= a->K && a->lda % 8 == 0, "ltxk_gemm_bf16: lda=%d (K=%d) must be >=K, multiple of 8", a->lda, a->K);
+  LTXK_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
+                 "ltxk_gemm_bf16: A/W must be 16-byte aligned, out 8-byte aligned");
+  const bool trans = a->out_tokens_per_batch > 0;
+  if (trans) {
+    LTXK_CHECK_ARG(a->epilogue == LTXK_EPI_BIAS, "ltxk_gemm_bf16: transposed output supports EPI_BIAS only");
+    LTXK_CHECK_ARG(a->M % a->out_tokens_per_batch == 0, "ltxk_gemm_bf16: M=%d not a multiple of tokens/batch=%d", a->M, a->out_tokens_per_batch);
+    LTXK_CHECK_ARG(a->ldo >= a->out_tokens_per_batch && a->ldo % 4 == 0, "ltxk_gemm_bf16: transposed ldo=%d", a->ldo);
+  } else {
+    LTXK_CHECK_ARG(a->ldo >= a->N && a->ldo % 4 == 0, "ltxk_gemm_bf16: ldo=%d (N=%d)", a->ldo, a->N);
+  }
+  if (a->epilogue == LTXK_EPI_BIAS_GATE_RES || a->epilogue == LTXK_EPI_BIAS_RES) {
+    LTXK_CHECK_ARG(a->resid != nullptr && a->ldr >= a->N && a->ldr % 4 == 0, "ltxk_gemm_bf16: residual epilogue needs resid/ldr");
+  }
+  if (a->epilogue == LTXK_EPI_BIAS_GATE_RES) {
+    LTXK_CHECK_ARG(a->gate != nullptr && a->gate_stride % 4 == 0, "ltxk_gemm_bf16: gate epilogue needs gate");
+  }
+  GemmParams p;
+  p.A = (const bf16*)a->A; p.W = (const bf16*)a->W; p.bias = (const bf16*)a->bias;
+  p.out = (bf16*)a->out; p.resid = (const bf16*)a->resid; p.gate = (const bf16*)a->gate;
+  p.gate_row = a->gate_row;
+  p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldo = a->ldo; p.ldr = a->ldr;
+  p.gate_stride = a->gate_stride; p.T = trans ? a->out_tokens_per_batch : 1;
+  const int tt = pick_tt(a->M, a->N);
+  const int bm = 32 * tt;
+  p.RT = (a->M + bm - 1) / bm;
+  p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
+  hipStream_t st = (hipStream_t)stream;
+  switch (tt) {
+    case 5: return dispatch_epi<5>(p, a->epilogue, trans, st);
+    case 4: return dispatch_epi<4>(p, a->epilogue, trans, st);
+    case 2: return dispatch_epi<2>(p, a->epilogue, trans, st);
+    default: return dispatch_epi<1>(p, a->epilogue, trans, st);
+  }
+}

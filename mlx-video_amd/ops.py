@@ -1,0 +1,149 @@
+"""torch.Tensor -> libltxk C-ABI call shims.  One function per entry point of include/ltxk.h.
+Tensors carry device memory only; all math happens in the HIP kernels.  Every call is queued
+on torch's current HIP stream (so a torch.cuda.graph capture records the whole step)."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 2, 3, 4
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.LtxkError(f"{name}: expected a device tensor (the product path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = EPI_BIAS,
+         out: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+         gate: Optional[torch.Tensor] = None, gate_row: Optional[torch.Tensor] = None,
+         gate_stride: int = 0, out_tokens_per_batch: int = 0) -> torch.Tensor:
+    """out = epi(a @ w.T + bias).  a (M,K) (row stride may exceed K), w (N,K) contiguous."""
+    _req(a, BF16, "gemm.a"); _req(w, BF16, "gemm.w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous() or a.stride(1) != 1:
+        raise ValueError(f"gemm: bad operand layout a{tuple(a.shape)} w{tuple(w.shape)}")
+    if out is None:
+        if out_tokens_per_batch:
+            raise ValueError("gemm: transposed output needs a preallocated `out`")
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    args = GemmArgs()
+    args.A, args.W, args.bias, args.out = _p(a), _p(w), _p(bias), _p(out)
+    args.resid, args.gate, args.gate_row = _p(resid), _p(gate), _p(gate_row)
+    args.M, args.N, args.K = M, N, K
+    args.lda = a.stride(0)
+    args.ldo = out.stride(-2)
+    args.ldr = resid.stride(0) if resid is not None else 0
+    args.gate_stride = gate_stride
+    args.epilogue = epilogue
+    args.out_tokens_per_batch = out_tokens_per_batch
+    check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
+    return out
+
+
+def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int,
+               Tq: int, Tk: int, scale: float) -> torch.Tensor:
+    """q (B*Tq, >=H*128) view, k (B*Tk, ...) view, vt (B, H*128, ldvt), out (B*Tq, H*128)."""
+    check(_lib.load().ltxk_flash_attn_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(-2),
+                                           _p(out), out.stride(0), B, H, Tq, Tk, scale, _stream()),
+          "ltxk_flash_attn_bf16")
+    return out
+
+
+def rmsnorm_modulate(x: torch.Tensor, eps: float, scale: Optional[torch.Tensor] = None,
+                     shift: Optional[torch.Tensor] = None, mod_stride: int = 0,
+                     mod_row: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, BF16, "rmsnorm_modulate.x")
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().ltxk_rmsnorm_modulate(_p(x), _p(out), M, D, eps, _p(scale), _p(shift), mod_stride,
+                                            _p(mod_row), _stream()), "ltxk_rmsnorm_modulate")
+    return out
+
+
+def layernorm_modulate(x: torch.Tensor, eps: float, scale: Optional[torch.Tensor] = None,
+                       shift: Optional[torch.Tensor] = None, mod_stride: int = 0,
+                       mod_row: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(x, BF16, "layernorm_modulate.x")
+    M, D = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().ltxk_layernorm_modulate(_p(x), _p(out), M, D, eps, _p(scale), _p(shift), mod_stride,
+                                              _p(mod_row), _stream()), "ltxk_layernorm_modulate")
+    return out
+
+
+def qknorm_rope(buf: torch.Tensor, nseg: int, D: int, weight: torch.Tensor, cos: Optional[torch.Tensor],
+                sin: Optional[torch.Tensor], T: int, H: int, eps: float) -> torch.Tensor:
+    """In place on the first nseg*D columns of buf (M, ld)."""
+    _req(buf, BF16, "qknorm_rope.buf")
+    if cos is not None and (cos.dtype != torch.float32 or not cos.is_contiguous()):
+        raise TypeError("qknorm_rope: cos/sin must be contiguous float32 (H,T,64)")
+    check(_lib.load().ltxk_qknorm_rope(_p(buf), buf.stride(0), buf.shape[0], nseg, D, _p(weight), _p(cos), _p(sin),
+                                       T, H, eps, _stream()), "ltxk_qknorm_rope")
+    return buf
+
+
+def timestep_embed(t: torch.Tensor, dim: int = 256) -> torch.Tensor:
+    _req(t, BF16, "timestep_embed.t")
+    out = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
+    check(_lib.load().ltxk_timestep_embed(_p(t), _p(out), t.numel(), dim, _stream()), "ltxk_timestep_embed")
+    return out
+
+
+def ada_combine(table: torch.Tensor, ada: torch.Tensor, L: int, U: int, K: int, D: int) -> torch.Tensor:
+    """table (L,K,D), ada (U,K*D) -> (L,U,K,D)."""
+    _req(table, BF16, "ada_combine.table"); _req(ada, BF16, "ada_combine.ada")
+    out = torch.empty((L, U, K, D), dtype=BF16, device=ada.device)
+    check(_lib.load().ltxk_ada_combine(_p(table), _p(ada), _p(out), L, U, K, D, _stream()), "ltxk_ada_combine")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _req(x, BF16, "silu.x")
+    out = torch.empty_like(x)
+    check(_lib.load().ltxk_silu(_p(x), _p(out), x.numel(), _stream()), "ltxk_silu")
+    return out
+
+
+def latent_to_tokens(latent: torch.Tensor, rep: int = 1) -> torch.Tensor:
+    """(B,C,F,H,W) or (B,C,S) -> (rep*B,S,C)."""
+    _req(latent, BF16, "latent_to_tokens.latent")
+    B, C = latent.shape[:2]
+    S = latent.numel() // (B * C)
+    lat = latent.contiguous()
+    out = torch.empty((rep * B, S, C), dtype=BF16, device=latent.device)
+    check(_lib.load().ltxk_latent_to_tokens(_p(lat), _p(out), B, C, S, rep, _stream()), "ltxk_latent_to_tokens")
+    return out
+
+
+def cfg_euler_step(v_pos: torch.Tensor, v_neg: Optional[torch.Tensor], latent: torch.Tensor, cfg_scale: float,
+                   sigma: float, sigma_next: float, clean: Optional[torch.Tensor] = None,
+                   mask_tok: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """v_* (B,S,C) tokens; latent (B,C,...) channels-first; mask_tok (B,S) float32."""
+    _req(latent, BF16, "cfg_euler_step.latent")
+    B, C = latent.shape[:2]
+    S = latent.numel() // (B * C)
+    if out is None:
+        out = torch.empty_like(latent)
+    check(_lib.load().ltxk_cfg_euler_step(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
+                                          B, C, S, cfg_scale, sigma, sigma_next, _stream()), "ltxk_cfg_euler_step")
+    return out
