@@ -108,9 +108,18 @@ int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
                      const void* weight, const float* cos, const float* sin,
                      int32_t T, int32_t H, float eps, void* stream);
 
-/* Sinusoidal timestep projection: utils.py:486-526 (flip_sin_to_cos, shift 0).
- * t: (U) bf16 timesteps (already * timestep_scale_multiplier); out: (U,dim) bf16.        */
-int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t dim, void* stream);
+/* Sinusoidal timestep projection: utils.py:486-526 (flip_sin_to_cos, shift 0), applied to
+ * bf16(t*mult) (ltx.py:68: timestep*timestep_scale_multiplier stays in the model dtype).
+ * t: (U) bf16 timesteps; out: (U,dim) bf16.                                              */
+int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t dim, float mult, void* stream);
+
+/* SPLIT-layout RoPE table, fp32: rope.py:419-529 (_precompute_freqs_cis_double_precision with
+ * use_middle_indices_grid).  positions: (3,T,2) fp32 [start,end); freq: (n_freq) fp32 =
+ * theta^linspace(0,1,n_freq)*pi/2 (host table, rope.py:449-450); max_pos: 3 HOST floats.
+ * cos/sin out: (H,T,dim/2/H) fp32; the first dim/2-3*n_freq entries are cos=1,sin=0.     */
+int ltxk_rope_table(const float* positions, const float* freq, float* cos, float* sin,
+                    int32_t T, int32_t H, int32_t dim, int32_t n_freq, const float* max_pos,
+                    void* stream);
 
 /* out[l,u,k,:] = bf16(table[l,k,:] + ada[u,k,:]): transformer.py:135-177, ltx.py:440-447. */
 int ltxk_ada_combine(const void* table, const void* ada, void* out, int32_t L, int32_t U,
@@ -133,6 +142,11 @@ int ltxk_latent_to_tokens(const void* latent, void* tokens, int32_t B, int32_t C
 int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent, void* out,
                         const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
                         float cfg_scale, float sigma, float sigma_next, void* stream);
+
+/* Euler update alone (eager path, generate.py:1293-1301, with un-rounded float sigmas):
+ * out = bf16(x0 + sigma_next*(x - x0)/sigma) in fp32; n elements, any layout.             */
+int ltxk_euler_step(const void* latent, const void* denoised, void* out, int64_t n,
+                    float sigma, float sigma_next, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,10 +47,13 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "ltxk_qknorm_rope": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_int32, c_int32, c_float, c_void_p]),
-    "ltxk_timestep_embed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "ltxk_timestep_embed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "ltxk_rope_table": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                  POINTER(c_float), c_void_p]),
     "ltxk_ada_combine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ltxk_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxk_latent_to_tokens": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ltxk_cfg_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_float, c_float, c_float, c_void_p]),
 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FaParams p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float e = __builtin_amdgcn_exp2f(s[kb][j] * p.c - mc);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][j], p.c, -mc));
         psum += e;
         pb[kb][j >> 3][j & 7] = (bf16)e;
       }
@@ -218,7 +218,7 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   p.c = scale * 1.4426950408889634f;
   static thread_local int attr_dev = -1;
   int dev = 0;
-  hipGetDevice(&dev);
+  (void)hipGetDevice(&dev);
   if (dev != attr_dev) {
     hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
     if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }

@@ -35,7 +35,15 @@ void ltxk_set_error(const char* fmt, ...);
   } while (0)
 
 // Round fp32 to bf16 storage and back: the "materialise a bf16 array" point of the reference.
-__device__ __forceinline__ float rbf(float x) { return (float)(bf16)x; }
+// Written as an opaque v_cvt_pk_bf16_f32 (RNE): with the plain cast pair hipcc (ROCm 7.2,
+// -ffp-contract=fast) narrows fptrunc(fmul(fpext a, fpext b)) to a bf16 multiply, re-promotes
+// it and then contracts it with the following add into one v_fmac_f32 — silently dropping the
+// rounding of the product.
+__device__ __forceinline__ float rbf(float x) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+  return __uint_as_float(r << 16);
+}
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // nn.gelu_approx: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))

@@ -152,15 +152,41 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
 // ---------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------
-__global__ void timestep_embed_kernel(const bf16* __restrict__ t, bf16* __restrict__ out, int U, int dim) {
+__global__ void timestep_embed_kernel(const bf16* __restrict__ t, bf16* __restrict__ out, int U, int dim, float mult) {
   const int half = dim >> 1;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= U * half) return;
   const int u = idx / half, i = idx - u * half;
   const float freq = expf(-9.210340371976184f * (float)i / (float)half);  // -ln(1e4)
-  const float arg = (float)t[u] * freq;
+  const float arg = rbf((float)t[u] * mult) * freq;   // timestep*1000 stays bf16 (ltx.py:68)
   out[(size_t)u * dim + i] = (bf16)cosf(arg);          // flip_sin_to_cos: cos first
   out[(size_t)u * dim + half + i] = (bf16)sinf(arg);
+}
+
+// RoPE table (SPLIT layout): rope.py:419-529.  f < pad: cos=1,sin=0 (front pad, rope.py:504-509);
+// else idx=(f-pad)/3, dim=(f-pad)%3; angle = ((mid/max_pos[dim])*2-1) * freq[idx].
+__global__ void rope_table_kernel(const float* __restrict__ pos, const float* __restrict__ freq,
+                                  float* __restrict__ cosb, float* __restrict__ sinb, int T, int H,
+                                  int half_dim, int pad, float mp0, float mp1, float mp2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * half_dim) return;
+  const int t = idx / half_dim, f = idx - t * half_dim;
+  float c = 1.f, s = 0.f;
+  if (f >= pad) {
+    const int fi = (f - pad) / 3, d = (f - pad) - fi * 3;
+    const float st = pos[((size_t)d * T + t) * 2], en = pos[((size_t)d * T + t) * 2 + 1];
+    const float mid = (st + en) / 2.0f;
+    const float mp = d == 0 ? mp0 : (d == 1 ? mp1 : mp2);
+    const float frac = __fdiv_rn(mid, mp);
+    const float ang = (frac * 2.0f - 1.0f) * freq[fi];
+    c = cosf(ang);
+    s = sinf(ang);
+  }
+  const int per_head = half_dim / H;
+  const int h = f / per_head, j = f - h * per_head;
+  const size_t o = ((size_t)h * T + t) * per_head + j;
+  cosb[o] = c;
+  sinb[o] = s;
 }
 
 __global__ void ada_combine_kernel(const bf16* __restrict__ table, const bf16* __restrict__ ada,
@@ -238,9 +264,35 @@ __global__ void cfg_euler_kernel(const bf16* __restrict__ vp, const bf16* __rest
   }
 }
 
+__global__ void euler_kernel(const bf16* __restrict__ x, const bf16* __restrict__ x0, bf16* __restrict__ out,
+                             int64_t n8, float sigma, float sigma_next) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  const bf16x8 a = *(const bf16x8*)(x + idx * 8);
+  const bf16x8 d = *(const bf16x8*)(x0 + idx * 8);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float df = (float)d[j];
+    o[j] = (bf16)(df + __fdiv_rn(sigma_next * ((float)a[j] - df), sigma));
+  }
+  *(bf16x8*)(out + idx * 8) = o;
+}
+
 }  // namespace ltxk
 
 using namespace ltxk;
+
+extern "C" int ltxk_euler_step(const void* latent, const void* denoised, void* out, int64_t n,
+                               float sigma, float sigma_next, void* stream) {
+  LTXK_CHECK_ARG(latent && denoised && out && n > 0 && n % 8 == 0, "ltxk_euler_step: n must be a positive multiple of 8");
+  LTXK_CHECK_ARG(sigma > 0.f, "ltxk_euler_step: sigma must be > 0");
+  const int64_t n8 = n / 8;
+  hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)latent, (const bf16*)denoised, (bf16*)out, n8, sigma, sigma_next);
+  LTXK_CHECK_LAUNCH("ltxk_euler_step");
+  return LTXK_OK;
+}
 
 static int norm_modulate_launch(bool ln, const void* x, void* y, int32_t M, int32_t D, float eps,
                                 const void* scale, const void* shift, int32_t mod_stride,
@@ -287,11 +339,26 @@ extern "C" int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, 
   return LTXK_OK;
 }
 
-extern "C" int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t dim, void* stream) {
+extern "C" int ltxk_rope_table(const float* positions, const float* freq, float* cos, float* sin,
+                               int32_t T, int32_t H, int32_t dim, int32_t n_freq, const float* max_pos,
+                               void* stream) {
+  LTXK_CHECK_ARG(positions && freq && cos && sin && max_pos, "ltxk_rope_table: null pointer");
+  LTXK_CHECK_ARG(T > 0 && H > 0 && dim % (2 * H) == 0, "ltxk_rope_table: bad dims");
+  const int half_dim = dim / 2;
+  const int pad = half_dim - 3 * n_freq;
+  LTXK_CHECK_ARG(pad >= 0, "ltxk_rope_table: 3*n_freq exceeds dim/2");
+  const int total = T * half_dim;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     positions, freq, cos, sin, T, H, half_dim, pad, max_pos[0], max_pos[1], max_pos[2]);
+  LTXK_CHECK_LAUNCH("ltxk_rope_table");
+  return LTXK_OK;
+}
+
+extern "C" int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t dim, float mult, void* stream) {
   LTXK_CHECK_ARG(t && out && U > 0 && dim > 0 && dim % 2 == 0, "ltxk_timestep_embed: bad arguments");
   const int total = U * (dim / 2);
   hipLaunchKernelGGL(timestep_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)t, (bf16*)out, U, dim);
+                     (const bf16*)t, (bf16*)out, U, dim, mult);
   LTXK_CHECK_LAUNCH("ltxk_timestep_embed");
   return LTXK_OK;
 }

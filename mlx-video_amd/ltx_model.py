@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's DiT seam: ``LTXModel.__call__(video: Modality, audio=None)``
+(mlx_video/models/ltx/ltx.py:459-506, transformer.py:13-22,247-261,342-347).
+
+Same names, argument meaning and error behaviour as the reference; every numeric op is a
+libltxk HIP kernel (``ops``).  Video-only (the audio / cross-modal branches are out of scope,
+SURVEY.md §2a #3).
+
+Data layout in HBM (per GPU, bf16 unless noted):
+  * weights: one contiguous (out,in) matrix per Linear, with to_q|to_k of the self-attention
+    packed into one (8192,4096) panel so q and k come out of one GEMM; 26 GB for L=48;
+  * tokens: (B*N, 4096) row-major residual stream, updated in place by the GEMM epilogues;
+  * AdaLN: instead of the reference's per-token (B,N,6*4096) tensor (63 MB at N=1280) the
+    ``U`` distinct timestep rows are embedded once — (L,U,6,4096) — and every kernel indexes it
+    with a (B*N) int32 token->row map.  Values are identical: each row of the reference's
+    per-token GEMM depends on that token's timestep only.
+  * V is produced transposed, (B, 4096, N_pad64), so attention reads it key-contiguous.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass(frozen=True)
+class Modality:
+    """transformer.py:13-22."""
+    latent: torch.Tensor                 # (B,N,128)
+    timesteps: torch.Tensor              # (B,N)  sigma*mask, model dtype
+    positions: Optional[torch.Tensor]    # (B,3,N,2) float32
+    context: torch.Tensor                # (B,S,3840)
+    enabled: bool = True
+    context_mask: Optional[torch.Tensor] = None
+    positional_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+
+
+@dataclass
+class LTXModelConfig:
+    """Video half of config.py:93-129 with the constants of generate.py:2866-2881."""
+    num_attention_heads: int = 32
+    attention_head_dim: int = 128
+    in_channels: int = 128
+    out_channels: int = 128
+    num_layers: int = 48
+    cross_attention_dim: int = 4096
+    caption_channels: int = 3840
+    positional_embedding_theta: float = 10000.0
+    positional_embedding_max_pos: Sequence[int] = (20, 2048, 2048)
+    use_middle_indices_grid: bool = True
+    rope_type: str = "split"
+    double_precision_rope: bool = True
+    timestep_scale_multiplier: int = 1000
+    norm_eps: float = 1e-6
+
+    @property
+    def inner_dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+@dataclass
+class TimestepPlan:
+    """The U distinct timestep values of a forward and the token -> row map."""
+    values: torch.Tensor     # (U,) bf16
+    tok2row: torch.Tensor    # (B*N,) int32
+
+    @staticmethod
+    def from_timesteps(timesteps: torch.Tensor) -> "TimestepPlan":
+        vals, inv = torch.unique(timesteps.reshape(-1), sorted=True, return_inverse=True)
+        return TimestepPlan(vals.to(BF16).contiguous(), inv.to(torch.int32).contiguous())
+
+
+def precompute_freqs_cis(positions: torch.Tensor, dim: int, theta: float = 10000.0,
+                         max_pos: Sequence[int] = (20, 2048, 2048), num_attention_heads: int = 32,
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rope.py:364-416 -> 419-529 (SPLIT, double_precision path, middle-indices grid).
+    positions (B,3,N,2) float32 on device.  Returns cos, sin (B,H,N,dim/H/2) float32.  The
+    per-index frequency vector theta^linspace(0,1,n)*pi/2 (682 floats) is a host table; the
+    (N x dim/2) trig table is a HIP kernel."""
+    if positions.dtype != torch.float32:
+        raise TypeError("position grid must be float32 (rope.py:433-441 warns on bfloat16)")
+    b, nd, n, two = positions.shape
+    if nd != 3 or two != 2:
+        raise ValueError(f"positions must be (B,3,N,2), got {tuple(positions.shape)}")
+    n_freq = max(dim // (2 * nd), 1)
+    lin = torch.linspace(0.0, 1.0, n_freq, dtype=torch.float32)
+    freq = (torch.pow(torch.tensor(theta, dtype=torch.float32), lin) * (math.pi / 2)).to(positions.device)
+    cos_l, sin_l = [], []
+    for i in range(b):
+        c, s = ops.rope_table(positions[i].contiguous(), freq, num_attention_heads, dim, max_pos)
+        cos_l.append(c)
+        sin_l.append(s)
+    return torch.stack(cos_l), torch.stack(sin_l)
+
+
+class _Block:
+    __slots__ = ("wqk", "bqk", "wv", "bv", "wnorm", "wo", "bo", "wq2", "bq2", "wk2", "bk2", "wv2", "bv2",
+                 "wqn2", "wkn2", "wo2", "bo2", "w1", "b1", "w2", "b2")
+
+
+class LTXModel:
+    """Velocity model.  ``model(video=Modality(...)) -> (velocity (B,N,128), None)``."""
+
+    def __init__(self, config: LTXModelConfig, weights: Dict[str, torch.Tensor]):
+        self.config = config
+        self.inner_dim = config.inner_dim
+        self.num_attention_heads = config.num_attention_heads
+        self.positional_embedding_theta = config.positional_embedding_theta
+        self.positional_embedding_max_pos = list(config.positional_embedding_max_pos)
+        self.use_middle_indices_grid = config.use_middle_indices_grid
+        self.rope_type = config.rope_type
+        self.timestep_scale_multiplier = config.timestep_scale_multiplier
+        self.cache_context = False          # reuse caption projection + ctx K/V across calls (same context tensor)
+        self._ctx_cache: Dict[int, tuple] = {}
+        self._pack(weights)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, W: Dict[str, torch.Tensor]) -> None:
+        cfg = self.config
+        missing = [k for k in self.expected_keys(cfg) if k not in W]
+        if missing:   # strict load (ltx.py:874-881)
+            raise ValueError(f"Missing {len(missing)} parameters in checkpoint, e.g. {missing[:4]}")
+
+        def g(k):
+            t = W[k]
+            if t.dtype != BF16 or not t.is_cuda:
+                raise TypeError(f"weight {k}: expected a bf16 device tensor")
+            return t.contiguous()
+
+        self.patchify_w, self.patchify_b = g("patchify_proj.weight"), g("patchify_proj.bias")
+        p = "adaln_single.emb.timestep_embedder"
+        self.t1_w, self.t1_b = g(f"{p}.linear1.weight"), g(f"{p}.linear1.bias")
+        self.t2_w, self.t2_b = g(f"{p}.linear2.weight"), g(f"{p}.linear2.bias")
+        self.ada_w, self.ada_b = g("adaln_single.linear.weight"), g("adaln_single.linear.bias")
+        self.c1_w, self.c1_b = g("caption_projection.linear1.weight"), g("caption_projection.linear1.bias")
+        self.c2_w, self.c2_b = g("caption_projection.linear2.weight"), g("caption_projection.linear2.bias")
+        self.head_table = g("scale_shift_table").reshape(1, 2, -1)
+        self.out_w, self.out_b = g("proj_out.weight"), g("proj_out.bias")
+        self.blocks: List[_Block] = []
+        tables = []
+        for i in range(cfg.num_layers):
+            pre = f"transformer_blocks.{i}"
+            b = _Block()
+            b.wqk = torch.cat([g(f"{pre}.attn1.to_q.weight"), g(f"{pre}.attn1.to_k.weight")], 0)
+            b.bqk = torch.cat([g(f"{pre}.attn1.to_q.bias"), g(f"{pre}.attn1.to_k.bias")], 0)
+            b.wv, b.bv = g(f"{pre}.attn1.to_v.weight"), g(f"{pre}.attn1.to_v.bias")
+            b.wnorm = torch.stack([g(f"{pre}.attn1.q_norm.weight"), g(f"{pre}.attn1.k_norm.weight")], 0)
+            b.wo, b.bo = g(f"{pre}.attn1.to_out.weight"), g(f"{pre}.attn1.to_out.bias")
+            b.wq2, b.bq2 = g(f"{pre}.attn2.to_q.weight"), g(f"{pre}.attn2.to_q.bias")
+            b.wk2, b.bk2 = g(f"{pre}.attn2.to_k.weight"), g(f"{pre}.attn2.to_k.bias")
+            b.wv2, b.bv2 = g(f"{pre}.attn2.to_v.weight"), g(f"{pre}.attn2.to_v.bias")
+            b.wqn2, b.wkn2 = g(f"{pre}.attn2.q_norm.weight"), g(f"{pre}.attn2.k_norm.weight")
+            b.wo2, b.bo2 = g(f"{pre}.attn2.to_out.weight"), g(f"{pre}.attn2.to_out.bias")
+            b.w1, b.b1 = g(f"{pre}.ff.proj_in.weight"), g(f"{pre}.ff.proj_in.bias")
+            b.w2, b.b2 = g(f"{pre}.ff.proj_out.weight"), g(f"{pre}.ff.proj_out.bias")
+            tables.append(g(f"{pre}.scale_shift_table"))
+            for nm in ("to_q", "to_k"):     # the packed copies replace these
+                W.pop(f"{pre}.attn1.{nm}.weight", None)
+            self.blocks.append(b)
+        self.tables = torch.stack(tables, 0).contiguous()      # (L,6,D)
+
+    @staticmethod
+    def expected_keys(cfg: LTXModelConfig) -> List[str]:
+        keys = []
+        for n in ("patchify_proj", "adaln_single.emb.timestep_embedder.linear1",
+                  "adaln_single.emb.timestep_embedder.linear2", "adaln_single.linear",
+                  "caption_projection.linear1", "caption_projection.linear2", "proj_out"):
+            keys += [f"{n}.weight", f"{n}.bias"]
+        keys.append("scale_shift_table")
+        for i in range(cfg.num_layers):
+            pre = f"transformer_blocks.{i}"
+            for a in ("attn1", "attn2"):
+                for nm in ("to_q", "to_k", "to_v", "to_out"):
+                    keys += [f"{pre}.{a}.{nm}.weight", f"{pre}.{a}.{nm}.bias"]
+                keys += [f"{pre}.{a}.q_norm.weight", f"{pre}.{a}.k_norm.weight"]
+            keys += [f"{pre}.ff.proj_in.weight", f"{pre}.ff.proj_in.bias",
+                     f"{pre}.ff.proj_out.weight", f"{pre}.ff.proj_out.bias", f"{pre}.scale_shift_table"]
+        return keys
+
+    @staticmethod
+    def sanitize(weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Checkpoint key map of ltx.py:508-533 (PyTorch LTX-2 names -> module names)."""
+        out = {}
+        for key, value in weights.items():
+            if (not key.startswith("model.diffusion_model.") or "audio_embeddings_connector" in key
+                    or "video_embeddings_connector" in key):
+                continue
+            k = key.replace("model.diffusion_model.", "")
+            k = k.replace(".to_out.0.", ".to_out.")
+            k = k.replace(".ff.net.0.proj.", ".ff.proj_in.").replace(".ff.net.2.", ".ff.proj_out.")
+            k = k.replace(".audio_ff.net.0.proj.", ".audio_ff.proj_in.").replace(".audio_ff.net.2.", ".audio_ff.proj_out.")
+            k = k.replace(".linear_1.", ".linear1.").replace(".linear_2.", ".linear2.")
+            out[k] = value
+        return out
+
+    @classmethod
+    def random_init(cls, config: LTXModelConfig, device, seed: int = 1234) -> "LTXModel":
+        """Random weights of the exact architecture, generated on the device (synthetic bench;
+        SURVEY.md §8d): Linear N(0,0.02^2), biases 0.01*N(0,1), tables N(0,0.02^2),
+        q/k-norm weights 1+0.1*N(0,1)."""
+        g = torch.Generator(device=device).manual_seed(seed)
+        D, FF = config.inner_dim, config.inner_dim * 4
+        W: Dict[str, torch.Tensor] = {}
+
+        def rn(*shape, std=1.0, mean=0.0):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std + mean).to(BF16)
+
+        def lin(name, o, i):
+            W[f"{name}.weight"] = rn(o, i, std=0.02)
+            W[f"{name}.bias"] = rn(o, std=0.01)
+
+        lin("patchify_proj", D, config.in_channels)
+        lin("adaln_single.emb.timestep_embedder.linear1", D, 256)
+        lin("adaln_single.emb.timestep_embedder.linear2", D, D)
+        lin("adaln_single.linear", 6 * D, D)
+        lin("caption_projection.linear1", D, config.caption_channels)
+        lin("caption_projection.linear2", D, D)
+        W["scale_shift_table"] = rn(2, D, std=0.02)
+        lin("proj_out", config.out_channels, D)
+        for i in range(config.num_layers):
+            pre = f"transformer_blocks.{i}"
+            for a in ("attn1", "attn2"):
+                for nm in ("to_q", "to_k", "to_v", "to_out"):
+                    lin(f"{pre}.{a}.{nm}", D, D)
+                W[f"{pre}.{a}.q_norm.weight"] = rn(D, std=0.1, mean=1.0)
+                W[f"{pre}.{a}.k_norm.weight"] = rn(D, std=0.1, mean=1.0)
+            lin(f"{pre}.ff.proj_in", FF, D)
+            lin(f"{pre}.ff.proj_out", D, FF)
+            W[f"{pre}.scale_shift_table"] = rn(6, D, std=0.02)
+        return cls(config, W)
+
+    # ------------------------------------------------------------------ forward
+    def _prepare_context(self, context: torch.Tensor) -> torch.Tensor:
+        """ltx.py:77-89: caption_projection, (B,S,3840) -> (B*S,D)."""
+        b, s, c = context.shape
+        h = ops.gemm(context.reshape(b * s, c), self.c1_w, self.c1_b, epilogue=ops.EPI_BIAS_GELU)
+        return ops.gemm(h, self.c2_w, self.c2_b)
+
+    def _context_kv(self, blk: _Block, ctx: torch.Tensor, b: int, s: int, sp: int):
+        D, H, eps = self.inner_dim, self.num_attention_heads, self.config.norm_eps
+        k2 = ops.gemm(ctx, blk.wk2, blk.bk2)
+        ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps)
+        vt2 = torch.zeros((b, D, sp), dtype=BF16, device=ctx.device) if sp != s else \
+            torch.empty((b, D, sp), dtype=BF16, device=ctx.device)
+        ops.gemm(ctx, blk.wv2, blk.bv2, out=vt2, out_tokens_per_batch=s)
+        return k2, vt2
+
+    def forward_tokens(self, latent: torch.Tensor, plan: TimestepPlan, context: torch.Tensor,
+                       pe: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+        """latent (B,N,128) bf16; context (B,S,3840) bf16; pe = (cos,sin) each (1|B,H,N,64) fp32
+        (one table shared by every batch row, as in cfg_batch where it is a broadcast,
+        generate.py:1196-1202)."""
+        cfg = self.config
+        D, H, eps = self.inner_dim, self.num_attention_heads, cfg.norm_eps
+        B, N, C = latent.shape
+        M = B * N
+        S = context.shape[1]
+        dev = latent.device
+        cos, sin = pe
+        if cos.dim() == 4:
+            cos, sin = cos[0], sin[0]
+        cos, sin = cos.contiguous(), sin.contiguous()
+        tok2row = plan.tok2row
+        U = plan.values.numel()
+        scale = 1.0 / math.sqrt(cfg.attention_head_dim)
+
+        # --- prepare (ltx.py:129-158) ---
+        x = ops.gemm(latent.reshape(M, C), self.patchify_w, self.patchify_b)
+        tproj = ops.timestep_embed(plan.values, 256, float(cfg.timestep_scale_multiplier))
+        h = ops.gemm(tproj, self.t1_w, self.t1_b, epilogue=ops.EPI_BIAS_SILU)
+        emb = ops.gemm(h, self.t2_w, self.t2_b)                           # embedded_timestep (U,D)
+        ada = ops.gemm(ops.silu(emb), self.ada_w, self.ada_b)             # (U,6D)
+        mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D)  # (L,U,6,D)
+        head = ops.ada_combine(self.head_table, emb.repeat(1, 2), 1, U, 2, D)[0]   # (U,2,D): shift, scale
+
+        ckey = context.data_ptr()
+        cached = self._ctx_cache.get(ckey) if self.cache_context else None
+        if cached is None:
+            ctx = self._prepare_context(context)
+            ctx_kv: List[Optional[tuple]] = [None] * cfg.num_layers
+            if self.cache_context:
+                self._ctx_cache = {ckey: (ctx, ctx_kv)}
+        else:
+            ctx, ctx_kv = cached
+
+        np64 = (N + 63) // 64 * 64
+        sp64 = (S + 63) // 64 * 64
+        vt = torch.zeros((B, D, np64), dtype=BF16, device=dev) if np64 != N else \
+            torch.empty((B, D, np64), dtype=BF16, device=dev)
+        qk = torch.empty((M, 2 * D), dtype=BF16, device=dev)
+        nx = torch.empty((M, D), dtype=BF16, device=dev)
+        att = torch.empty((M, D), dtype=BF16, device=dev)
+        q2 = torch.empty((M, D), dtype=BF16, device=dev)
+        hff = torch.empty((M, 4 * D), dtype=BF16, device=dev)
+        ms = 6 * D
+
+        for li, blk in enumerate(self.blocks):
+            mod = mods[li]                                           # (U,6,D): shift,scale,gate x2
+            # self-attention (transformer.py:248-254)
+            ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx)
+            ops.gemm(nx, blk.wqk, blk.bqk, out=qk)
+            ops.gemm(nx, blk.wv, blk.bv, out=vt, out_tokens_per_batch=N)
+            ops.qknorm_rope(qk, 2, D, blk.wnorm, cos, sin, N, H, eps)
+            ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale)
+            ops.gemm(att, blk.wo, blk.bo, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
+                     gate=mod[:, 2], gate_row=tok2row, gate_stride=ms)
+            # text cross-attention (transformer.py:257-261)
+            ops.rmsnorm_modulate(x, eps, out=nx)
+            ops.gemm(nx, blk.wq2, blk.bq2, out=q2)
+            ops.qknorm_rope(q2, 1, D, blk.wqn2, None, None, N, H, eps)
+            kv = ctx_kv[li]
+            if kv is None:
+                kv = self._context_kv(blk, ctx, B, S, sp64)
+                if self.cache_context:
+                    ctx_kv[li] = kv
+            ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale)
+            ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x)
+            # feed-forward (transformer.py:343-347)
+            ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx)
+            ops.gemm(nx, blk.w1, blk.b1, epilogue=ops.EPI_BIAS_GELU, out=hff)
+            ops.gemm(hff, blk.w2, blk.b2, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
+                     gate=mod[:, 5], gate_row=tok2row, gate_stride=ms)
+
+        # --- output head (ltx.py:432-457) ---
+        ops.layernorm_modulate(x, eps, head[:, 1], head[:, 0], 2 * D, tok2row, out=nx)
+        v = ops.gemm(nx, self.out_w, self.out_b)
+        return v.reshape(B, N, cfg.out_channels)
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None):
+        if audio is not None:
+            raise ValueError("Audio is not enabled for this model")      # ltx.py:468-469
+        if video is None:
+            return None, None
+        lat = video.latent
+        if lat.dim() != 3 or lat.shape[-1] != self.config.in_channels:
+            raise ValueError(f"latent must be (B,N,{self.config.in_channels}), got {tuple(lat.shape)}")
+        if video.context_mask is not None:
+            raise ValueError("context_mask is not supported on this path (the reference passes None, generate.py:800)")
+        pe = video.positional_embeddings
+        if pe is None:
+            pe = precompute_freqs_cis(video.positions, self.inner_dim, self.positional_embedding_theta,
+                                      self.positional_embedding_max_pos, self.num_attention_heads)
+        plan = TimestepPlan.from_timesteps(video.timesteps.to(BF16))
+        v = self.forward_tokens(lat.to(BF16).contiguous(), plan, video.context.to(BF16).contiguous(), pe)
+        return v, None
+
+
+class X0Model:
+    """ltx.py:888-906: velocity -> denoised wrapper (per-token sigma = timesteps)."""
+
+    def __init__(self, velocity_model: LTXModel):
+        self.velocity_model = velocity_model
+
+    def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None):
+        raise NotImplementedError("X0Model is only used by the reference's legacy ltx_pipelines/utils helpers "
+                                  "(dead code there, SURVEY.md §2a #14); use denoise.denoise_dev/denoise_distilled")

@@ -102,11 +102,23 @@ def qknorm_rope(buf: torch.Tensor, nseg: int, D: int, weight: torch.Tensor, cos:
     return buf
 
 
-def timestep_embed(t: torch.Tensor, dim: int = 256) -> torch.Tensor:
+def timestep_embed(t: torch.Tensor, dim: int = 256, mult: float = 1.0) -> torch.Tensor:
     _req(t, BF16, "timestep_embed.t")
     out = torch.empty((t.numel(), dim), dtype=BF16, device=t.device)
-    check(_lib.load().ltxk_timestep_embed(_p(t), _p(out), t.numel(), dim, _stream()), "ltxk_timestep_embed")
+    check(_lib.load().ltxk_timestep_embed(_p(t), _p(out), t.numel(), dim, mult, _stream()), "ltxk_timestep_embed")
     return out
+
+
+def rope_table(positions: torch.Tensor, freq: torch.Tensor, H: int, dim: int, max_pos) -> tuple:
+    """positions (3,T,2) fp32, freq (n_freq) fp32 -> cos, sin (H,T,dim/2/H) fp32."""
+    T = positions.shape[1]
+    per_head = dim // 2 // H
+    cos = torch.empty((H, T, per_head), dtype=torch.float32, device=positions.device)
+    sin = torch.empty_like(cos)
+    mp = (ctypes.c_float * 3)(*[float(v) for v in max_pos])
+    check(_lib.load().ltxk_rope_table(_p(positions), _p(freq), _p(cos), _p(sin), T, H, dim, freq.numel(), mp,
+                                      _stream()), "ltxk_rope_table")
+    return cos, sin
 
 
 def ada_combine(table: torch.Tensor, ada: torch.Tensor, L: int, U: int, K: int, D: int) -> torch.Tensor:
@@ -146,4 +158,12 @@ def cfg_euler_step(v_pos: torch.Tensor, v_neg: Optional[torch.Tensor], latent: t
         out = torch.empty_like(latent)
     check(_lib.load().ltxk_cfg_euler_step(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
                                           B, C, S, cfg_scale, sigma, sigma_next, _stream()), "ltxk_cfg_euler_step")
+    return out
+
+
+def euler_only(latent: torch.Tensor, denoised: torch.Tensor, sigma: float, sigma_next: float) -> torch.Tensor:
+    _req(latent, BF16, "euler_only.latent"); _req(denoised, BF16, "euler_only.denoised")
+    out = torch.empty_like(latent)
+    check(_lib.load().ltxk_euler_step(_p(latent.contiguous()), _p(denoised.contiguous()), _p(out), latent.numel(),
+                                      sigma, sigma_next, _stream()), "ltxk_euler_step")
     return out
