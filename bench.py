@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — LTX-2 19B dev denoise step (512x512x33, CFG 4.0, bf16) + video-VAE decode on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = the whole body of denoise_dev's loop (mlx_video/generate.py:1227-1304) at
+BASELINE.json configs[1]: latent (1,128,5,16,16) -> N=1280 tokens, 48 blocks, D=4096, text
+context 2x(1024x3840), cfg_batch (pos/neg branches as one B=2 forward, the CLI default,
+generate.py:4643), CFG 4.0, x0 + Euler.  Nothing is cached across steps in the timed region:
+caption projection and the text-context K/V projections are recomputed every forward exactly
+as the reference does (SURVEY.md §8d counts them in the 69.7 TFLOP/step).  Synthetic inputs,
+random-init weights of the exact architecture (no checkpoints exist offline).
+
+Multi-GPU (weak scaling): every rank denoises its own seed with a full weight replica — the
+path shards over independent forwards only; no data-path collective.  The
+CFG-pair split with an RCCL all-gather of velocities (config 4) is `--shard cfgpair`.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level table)
+PEAK_HBM_GBS = 8000.0
+
+
+def dit_forward_flops(N: int, B: int = 1, D: int = 4096, FF: int = 16384, S: int = 1024, L: int = 48) -> float:
+    """SURVEY.md §8d algorithmic FLOPs (2*MAC) of one DiT forward, per batch row, times B."""
+    per_block = 12 * N * D * D + 4 * N * D * FF + 4 * S * D * D + 4 * N * N * D + 4 * N * S * D
+    extra = 2 * N * (256 * D + D * D + 6 * D * D) + 2 * S * (3840 * D + D * D) + 4 * N * 128 * D
+    return float(B) * (L * per_block + extra)
+
+
+def cpu_baseline_block(threads: int):
+    """CPU baseline (kind "port"): the oracle's transformer block, fp32, at the bench shape
+    (B=2 CFG pair, N=1280, S=1024, D=4096) — 1 of the 48 blocks, scaled x48 to steps/s."""
+    from oracle import dit as O
+    torch.set_num_threads(threads)
+    cfg = O.DiTConfig(num_layers=1)
+    W = O.make_weights(cfg, seed=1234, dtype=torch.float32)
+    g = torch.Generator().manual_seed(42)
+    B, N, S, D = 2, 1280, 1024, cfg.dim
+    x = torch.randn(B, N, D, generator=g)
+    ts = torch.randn(B, N, 6 * D, generator=g) * 0.02
+    ctx = torch.randn(B, S, D, generator=g)
+    pos = torch.from_numpy(O.create_position_grid(1, 5, 16, 16))
+    cos, sin = O.precompute_freqs_cis(pos, D)
+    cos, sin = cos.expand(B, -1, -1, -1), sin.expand(B, -1, -1, -1)
+    t0 = time.perf_counter()
+    O.transformer_block(x, ts, ctx, (cos, sin), W, 0, cfg, O.F32)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * 48), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 of 48 DiT blocks (oracle fp32, B=2 CFG pair, N=1280, S=1024, D=4096) = {dt:.2f} s, scaled x48"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=48, help="debug only; the reported config is always 48")
+    ap.add_argument("--frames", type=int, default=33)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--shard", choices=["seeds", "cfgpair"], default="seeds")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--cache-context", action="store_true", help="reuse ctx K/V across steps (reported separately)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    from mlx_video_amd import ops
+    from mlx_video_amd.denoise import denoise_dev
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+    from mlx_video_amd.schedulers import create_position_grid, ltx2_scheduler
+
+    cfg = LTXModelConfig(num_layers=args.layers)
+    model = LTXModel.random_init(cfg, dev, seed=1234)
+    model.cache_context = args.cache_context
+    Fl, Hl, Wl = 1 + (args.frames - 1) // 8, args.height // 32, args.width // 32
+    N = Fl * Hl * Wl
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    latents = torch.randn((1, 128, Fl, Hl, Wl), generator=g, device=dev).to(torch.bfloat16)
+    g2 = torch.Generator(device=dev).manual_seed(43)
+    ctx_pos = torch.randn((1, 1024, 3840), generator=g2, device=dev).to(torch.bfloat16)
+    ctx_neg = torch.randn((1, 1024, 3840), generator=g2, device=dev).to(torch.bfloat16)
+    positions = create_position_grid(1, Fl, Hl, Wl).to(dev)
+    sig_all = ltx2_scheduler(40, N)
+
+    pg_shard = None
+    if args.shard == "cfgpair" and world > 1:
+        from mlx_video_amd.sharding import CfgPairSharding
+        pg_shard = CfgPairSharding(dist, rank, world)
+
+    def run_steps(k: int, start: int = 0):
+        # k consecutive steps of the 40-step schedule (sigma values only select scalars; cost is step-invariant)
+        s = sig_all[start:start + k + 1].clone()
+        if pg_shard is not None:
+            return pg_shard.denoise_dev(latents, positions, ctx_pos, ctx_neg, model, s, cfg_scale=4.0)
+        return denoise_dev(latents, positions, ctx_pos, ctx_neg, model, s, cfg_scale=4.0, compile_step=True,
+                           cfg_batch=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    barrier()
+    ops.TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    out = run_steps(args.steps, start=min(args.warmup, 40 - args.steps))
+    barrier()
+    dt = time.perf_counter() - t0
+    timer, ops.TIMER = ops.TIMER, None
+    if not torch.isfinite(out.float()).all():
+        raise SystemExit("non-finite latents after the timed steps")
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    seeds = world if pg_shard is None else max(world // 2, 1)
+    steps_per_s = seeds * args.steps / dt
+    fams = timer.summary()
+
+    result = {
+        "metric": "denoise steps/sec/GPU + VAE frames/sec, LTX-2 19B 512x512x33 bf16",
+        "value": steps_per_s,
+        "unit": "denoise steps/s (whole job; one step = 2 CFG forwards + CFG + x0 + Euler)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init weights of the LTX-2 video DiT, N(0,1) latents/context)",
+        "config": {"workload": f"LTX-2 19B dev {args.width}x{args.height}x{args.frames}, CFG 4.0, cfg_batch, "
+                               f"N={N} tokens, L={args.layers}, ctx 1024x3840, {args.shard} sharding",
+                   "global_batch": seeds, "tokens": N, "parallelism": f"{args.shard}{world}",
+                   "ctx_kv_cached": bool(args.cache_context)},
+    }
+    step_flops = dit_forward_flops(N, B=2, L=args.layers)
+    result["step_tflop"] = step_flops / 1e12
+    result["achieved_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12 * (1 if pg_shard is None else 0.5)
+    if "gemm_bf16" in fams:
+        gm = fams["gemm_bf16"]
+        ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "ltxk::gemm_bf16_kernel (all Linear layers)", "bound": "mfma",
+                              "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                              "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"]}
+    result["kernel_breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fams.items()}
+    if "flash_attn" in fams:
+        fa = fams["flash_attn"]
+        result["attention_tflops"] = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
+    for k in ("rmsnorm_modulate", "qknorm_rope"):
+        if k in fams and fams[k]["ms"] > 0:
+            result[f"{k}_GBs"] = fams[k]["bytes"] / (fams[k]["ms"] * 1e-3) / 1e9
+
+    if not args.no_vae:
+        try:
+            from mlx_video_amd import video_vae
+            result.update(video_vae.bench_decode(dev, Fl, Hl, Wl))
+        except ImportError:
+            result["vae_decode_fps"] = None
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del model
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline_block(min(len(os.sched_getaffinity(0)), 16))
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,6 +15,46 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 
 BF16 = torch.bfloat16
 
 
+class KernelTimer:
+    """Optional per-launch HIP-event timing (bench.py roofline leg).  Events are recorded on the
+    stream the kernels are launched on; nothing is synchronised until ``summary()``."""
+
+    def __init__(self):
+        self.records = []       # (family, algorithmic flops, algorithmic bytes, start, end)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for fam, flops, nbytes, s, e in self.records:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+class _timed:
+    __slots__ = ("fam", "flops", "nbytes", "s")
+
+    def __init__(self, fam, flops=0.0, nbytes=0.0):
+        self.fam, self.flops, self.nbytes = fam, flops, nbytes
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if TIMER is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            TIMER.records.append((self.fam, self.flops, self.nbytes, self.s, e))
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -54,16 +94,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
     args.gate_stride = gate_stride
     args.epilogue = epilogue
     args.out_tokens_per_batch = out_tokens_per_batch
-    check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
+    with _timed("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+        check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
     return out
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int,
                Tq: int, Tk: int, scale: float) -> torch.Tensor:
     """q (B*Tq, >=H*128) view, k (B*Tk, ...) view, vt (B, H*128, ldvt), out (B*Tq, H*128)."""
-    check(_lib.load().ltxk_flash_attn_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(-2),
-                                           _p(out), out.stride(0), B, H, Tq, Tk, scale, _stream()),
-          "ltxk_flash_attn_bf16")
+    with _timed("flash_attn", 4.0 * B * H * Tq * Tk * 128, 2.0 * B * H * 128 * (2 * Tq + 2 * Tk)):
+        check(_lib.load().ltxk_flash_attn_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(-2),
+                                               _p(out), out.stride(0), B, H, Tq, Tk, scale, _stream()),
+              "ltxk_flash_attn_bf16")
     return out
 
 
@@ -74,8 +116,9 @@ def rmsnorm_modulate(x: torch.Tensor, eps: float, scale: Optional[torch.Tensor] 
     M, D = x.shape
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.load().ltxk_rmsnorm_modulate(_p(x), _p(out), M, D, eps, _p(scale), _p(shift), mod_stride,
-                                            _p(mod_row), _stream()), "ltxk_rmsnorm_modulate")
+    with _timed("rmsnorm_modulate", 0.0, 4.0 * M * D):
+        check(_lib.load().ltxk_rmsnorm_modulate(_p(x), _p(out), M, D, eps, _p(scale), _p(shift), mod_stride,
+                                                _p(mod_row), _stream()), "ltxk_rmsnorm_modulate")
     return out
 
 
@@ -97,8 +140,9 @@ def qknorm_rope(buf: torch.Tensor, nseg: int, D: int, weight: torch.Tensor, cos:
     _req(buf, BF16, "qknorm_rope.buf")
     if cos is not None and (cos.dtype != torch.float32 or not cos.is_contiguous()):
         raise TypeError("qknorm_rope: cos/sin must be contiguous float32 (H,T,64)")
-    check(_lib.load().ltxk_qknorm_rope(_p(buf), buf.stride(0), buf.shape[0], nseg, D, _p(weight), _p(cos), _p(sin),
-                                       T, H, eps, _stream()), "ltxk_qknorm_rope")
+    with _timed("qknorm_rope", 0.0, 4.0 * buf.shape[0] * nseg * D + (8.0 * buf.shape[0] * D // 2 if cos is not None else 0.0)):
+        check(_lib.load().ltxk_qknorm_rope(_p(buf), buf.stride(0), buf.shape[0], nseg, D, _p(weight), _p(cos), _p(sin),
+                                           T, H, eps, _stream()), "ltxk_qknorm_rope")
     return buf
 
 
