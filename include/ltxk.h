@@ -148,6 +148,79 @@ int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent
 int ltxk_euler_step(const void* latent, const void* denoised, void* out, int64_t n,
                     float sigma, float sigma_next, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Video VAE (volumes are channels-last (B,D,H,W,C) bf16; a row = one voxel)
+ * ------------------------------------------------------------------------------------- */
+enum { LTXK_PAD_ZEROS = 0, LTXK_PAD_REFLECT = 1 };
+
+typedef struct ltxk_conv3d_args {
+  const void* x;         /* (B,D,H,W,Cin) bf16, Cin % 64 == 0                              */
+  const void* w;         /* (Cout,3,3,3,Cin) bf16 (MLX layout, decoder.py:708-710)         */
+  const void* bias;      /* (Cout) bf16                                                    */
+  void* out;             /* (B,D,H,W,Cout) bf16                                            */
+  const void* resid;     /* optional (B,D,H,W,Cout): out = bf16(conv + resid) (decoder.py:180) */
+  const void* zero_page; /* >= 128 zero bytes in device memory (zero-padding source)       */
+  int32_t B, D, H, W, Cin, Cout;
+  int32_t causal;        /* temporal halo: 1 = 2x first frame; 0 = first + last (convolution.py:126-137) */
+  int32_t pad_mode;      /* spatial halo: LTXK_PAD_ZEROS | LTXK_PAD_REFLECT (convolution.py:143-157) */
+} ltxk_conv3d_args;
+
+/* nn.Conv3d 3x3x3 stride 1 inside CausalConv3d (convolution.py:78-222) as implicit GEMM.   */
+int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* args, void* stream);
+
+/* pixel_norm over channels [+ (1+scale)+shift per (batch,channel)] [+ SiLU]: decoder.py:136-180,
+ * 415-437; utils.py:477-483.  x,y: (V,C) rows = voxels, C in {64..2048, power of two}.
+ * scale/shift: (B,C) bf16 or NULL; rows_per_batch = D*H*W.                                 */
+int ltxk_pixelnorm_act(const void* x, void* y, int64_t V, int32_t C, float eps, const void* scale,
+                       const void* shift, int64_t rows_per_batch, int32_t apply_silu, void* stream);
+
+/* DepthToSpaceUpsample tail (sampling.py:143-197): conv (B,D,H,W,8*Co) -> out (B,2D-1,2H,2W,Co),
+ * channel (c,st,sh,sw), first output frame dropped, plus the residual d2s(xin) tiled over
+ * channels (xin (B,D,H,W,Ci) or NULL).                                                     */
+int ltxk_d2s_add(const void* conv, const void* xin, void* out, int32_t B, int32_t D, int32_t H, int32_t W,
+                 int32_t Co, int32_t Ci, void* stream);
+
+/* SpaceToDepthDownsample tail (sampling.py:53-103): conv (B,Dp,Hp,Wp,Cc) and the (front-frame
+ * duplicated) input xpad (B,Dp,Hp,Wp,Cx) -> out (B,Dp/st,Hp/sh,Wp/sw,Cc*st*sh*sw) =
+ * s2d(conv) + group-mean_G(s2d(xpad)), G = Cx/Cc.                                          */
+int ltxk_s2d_skip(const void* conv, const void* xpad, void* out, int32_t B, int32_t Dp, int32_t Hp,
+                  int32_t Wp, int32_t Cc, int32_t Cx, int32_t st, int32_t sh, int32_t sw, int32_t G,
+                  void* stream);
+
+/* latents (B,C,S) channels-first -> (B,S,C) channels-last with fp32 x*std+mean (decoder.py:349-355). */
+int ltxk_latent_denorm_cl(const void* latent, const void* mean, const void* std, void* out,
+                          int32_t B, int32_t C, int64_t S, void* stream);
+
+/* (B,S,ldx>=C) channels-last -> (B,C,S) channels-first with fp32 (x-mean)/std (ops.py:94-109). */
+int ltxk_latent_norm_cf(const void* x, int32_t ldx, const void* mean, const void* std, void* out,
+                        int32_t B, int32_t C, int64_t S, void* stream);
+
+/* conv_out (B,D,H,W,C*P*P) channels-last -> unpatchify (ops.py:47-80, channel order (c,p_w,p_h))
+ * -> video (B,C,D,H*P,W*P) channels-first.  Bit-exact index map.                           */
+int ltxk_unpatchify_cf(const void* x, void* out, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                       int32_t P, void* stream);
+
+/* video (B,C,D,H,W) -> patchify (ops.py:9-44) -> (B,D,H/P,W/P,Cpad) channels-last, channels
+ * beyond C*P*P zero (pads 48 -> 64 for the first encoder convolution).                     */
+int ltxk_patchify_cl(const void* video, void* out, int32_t B, int32_t C, int32_t D, int32_t H, int32_t W,
+                     int32_t P, int32_t Cpad, void* stream);
+
+/* video (B,C,F,H,W) bf16 in [-1,1] -> uint8 frames (B,F,H,W,C): generate.py:3894-3898.     */
+int ltxk_to_uint8(const void* x, void* out, int32_t B, int32_t C, int32_t F, int32_t H, int32_t W,
+                  void* stream);
+
+/* Tiled-decode blending (tiling.py:399-447): acc[b,c,t0+t,h0+y,w0+x] += tile[b,c,t,y,x]*m,
+ * wsum[b,t0+t,h0+y,w0+x] += m with m = mt[t]*mh[y]*mw[x]; tile (B,C,Tt,Th,Tw) bf16 of which the
+ * leading (at,ah,aw) box is used; acc (B,C,F,H,W) / wsum (B,F,H,W) fp32.                    */
+int ltxk_tile_blend_accum(const void* tile, int32_t Tt, int32_t Th, int32_t Tw, int32_t at, int32_t ah,
+                          int32_t aw, const float* mt, const float* mh, const float* mw, float* acc,
+                          float* wsum, int32_t B, int32_t C, int32_t F, int32_t H, int32_t W, int32_t t0,
+                          int32_t h0, int32_t w0, void* stream);
+
+/* out = bf16(acc / max(wsum, 1e-8)) (tiling.py:492-509); S = F*H*W.                         */
+int ltxk_tile_blend_finalize(const float* acc, const float* wsum, void* out, int32_t B, int32_t C,
+                             int64_t S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ class Conv3dArgs(Structure):
         ("resid", c_void_p), ("zero_page", c_void_p),
         ("B", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
         ("Cin", c_int32), ("Cout", c_int32),
-        ("causal", c_int32), ("pad_mode", c_int32), ("d2s", c_int32),
+        ("causal", c_int32), ("pad_mode", c_int32),
     ]
 
 
@@ -53,6 +53,22 @@ SIGNATURES = {
     "ltxk_ada_combine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ltxk_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxk_latent_to_tokens": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_conv3d_k3_bf16": (c_int32, [POINTER(Conv3dArgs), c_void_p]),
+    "ltxk_pixelnorm_act": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_int64,
+                                     c_int32, c_void_p]),
+    "ltxk_d2s_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                               c_void_p]),
+    "ltxk_s2d_skip": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p]),
+    "ltxk_latent_denorm_cl": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
+    "ltxk_latent_norm_cf": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
+                                      c_void_p]),
+    "ltxk_unpatchify_cf": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                     c_void_p]),
+    "ltxk_patchify_cl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                   c_void_p]),
+    "ltxk_to_uint8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_tile_blend_accum": (c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 8 + [c_void_p]),
+    "ltxk_tile_blend_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "ltxk_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ltxk_cfg_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_float, c_float, c_float, c_void_p]),

@@ -1,0 +1,179 @@
+// 3x3x3 stride-1 convolution of the video VAE as an implicit GEMM on MFMA: ltxk_conv3d_k3_bf16.
+// Replaces nn.Conv3d inside CausalConv3d (video_vae/convolution.py:111-118,161) including its
+// halo handling (convolution.py:120-157): temporal pad by frame replication (causal: two copies
+// of the first frame; non-causal: first + last), spatial pad reflect (decoder) or zeros
+// (encoder).  No padded copy of the volume is ever materialised: the halo is resolved in the
+// per-lane SOURCE address of the LDS-DMA tile loads (a row gather), zero padding reads a
+// caller-provided zero page.
+//
+//   out[v, co] = bias[co] + sum_{tap, ci} x[src(v, tap), ci] * w[co, tap, ci]
+//   M = B*D*H*W voxels (channels-last rows), N = Cout, K = 27*Cin walked tap-major in 64-wide
+//   steps; same 3-stage LDS ring / MFMA loop as the Linear GEMM (gemm_core.h).
+#include "gemm_core.h"
+
+namespace ltxk {
+
+struct ConvParams {
+  const bf16* x; const bf16* w; const bf16* bias; bf16* out; const bf16* resid; const bf16* zero;
+  int B, D, H, W, Cin, Cout;
+  int causal, pad_mode;
+  int M, RT, CT, cpb;   // cpb = Cin/64 K-steps per tap
+};
+
+template <int TT, int WN, bool RES>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
+  using G = GemmGeom<TT, WN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ct = blockIdx.x % p.CT, rt = blockIdx.x / p.CT;
+  const int m0 = rt * G::BM, n0 = ct * G::BN;
+  const int K = 27 * p.Cin;
+
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const bf16* wptr[G::W_PER_WAVE];
+#pragma unroll
+  for (int i = 0; i < G::W_PER_WAVE; ++i) {
+    int r = n0 + (wave * G::W_PER_WAVE + i) * 8 + lrow;
+    r = r < p.Cout ? r : p.Cout - 1;
+    wptr[i] = p.w + (size_t)r * K + chunk * 8;
+  }
+  const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
+  const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
+  int vb[G::MAXA], vd[G::MAXA], vh[G::MAXA], vw[G::MAXA];
+#pragma unroll
+  for (int i = 0; i < G::MAXA; ++i) {
+    int r = m0 + (a0 + i) * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    vw[i] = r % p.W; r /= p.W;
+    vh[i] = r % p.H; r /= p.H;
+    vd[i] = r % p.D; vb[i] = r / p.D;
+  }
+  const int per_stage = G::W_PER_WAVE + nA;
+  const bf16* zsrc = p.zero + chunk * 8;
+
+  auto issue = [&](int kt, int s) {
+    char* base = smem + s * G::STAGE_BYTES;
+    const int tap = kt / p.cpb, cb = kt - tap * p.cpb;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+    for (int i = 0; i < G::W_PER_WAVE; ++i)
+      glds16(wptr[i] + kt * GEMM_BK, base + (wave * G::W_PER_WAVE + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < G::MAXA; ++i)
+      if (i < nA) {
+        int d = vd[i] + kd - (p.causal ? 2 : 1);
+        d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
+        int h = vh[i] + kh - 1, w = vw[i] + kw - 1;
+        bool zero = false;
+        if (p.pad_mode == LTXK_PAD_REFLECT) {
+          h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
+          w = w < 0 ? 1 : (w >= p.W ? p.W - 2 : w);
+        } else {
+          zero = (h < 0) | (h >= p.H) | (w < 0) | (w >= p.W);
+        }
+        const size_t vox = (((size_t)vb[i] * p.D + d) * p.H + h) * p.W + w;
+        const bf16* src = zero ? zsrc : p.x + vox * p.Cin + cb * 64 + chunk * 8;
+        glds16(src, base + G::W_STAGE_BYTES + (a0 + i) * 1024);
+      }
+  };
+
+  f32x4 acc[TT][4];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = 27 * p.cpb;
+  issue(0, 0);
+  issue(1, 1);
+  int s = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_stage_and_barrier(kt + 1 < nk ? per_stage : 0);
+    if (kt + 2 < nk) {
+      int s2 = s + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      issue(kt + 2, s2);
+    }
+    mma_stage<TT, WN, false>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
+    s = s + 1 == 3 ? 0 : s + 1;
+  }
+
+  // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j
+  const int nq = (lane >> 4) * 4;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + nq;
+      if (n >= p.Cout) continue;
+      const bf16x4 b = *(const bf16x4*)(p.bias + n);
+      float y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
+      if constexpr (RES) {
+        const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.Cout + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = y[j] + (float)r[j];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+      *(bf16x4*)(p.out + (size_t)m * p.Cout + n) = o;
+    }
+  }
+}
+
+template <int TT, int WN, bool RES>
+static int conv_launch(const ConvParams& p, hipStream_t stream) {
+  using G = GemmGeom<TT, WN>;
+  auto kern = conv3d_k3_kernel<TT, WN, RES>;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_conv3d_k3_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_dev = dev;
+  }
+  ConvParams q = p;
+  q.RT = (p.M + G::BM - 1) / G::BM;
+  q.CT = (p.Cout + G::BN - 1) / G::BN;
+  hipLaunchKernelGGL(kern, dim3(q.RT * q.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, q);
+  LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16");
+  return LTXK_OK;
+}
+
+}  // namespace ltxk
+
+extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
+  using namespace ltxk;
+  LTXK_CHECK_ARG(a != nullptr, "ltxk_conv3d_k3_bf16: null args");
+  LTXK_CHECK_ARG(a->x && a->w && a->bias && a->out && a->zero_page, "ltxk_conv3d_k3_bf16: null x/w/bias/out/zero_page");
+  LTXK_CHECK_ARG(a->B > 0 && a->D > 0 && a->H >= 2 && a->W >= 2, "ltxk_conv3d_k3_bf16: bad volume %dx%dx%dx%d", a->B, a->D, a->H, a->W);
+  LTXK_CHECK_ARG(a->Cin % 64 == 0 && a->Cin > 0, "ltxk_conv3d_k3_bf16: Cin=%d must be a multiple of 64 (pad channels with zeros)", a->Cin);
+  LTXK_CHECK_ARG(a->Cout % 8 == 0 && a->Cout > 0, "ltxk_conv3d_k3_bf16: Cout=%d must be a multiple of 8", a->Cout);
+  LTXK_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->zero_page) & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
+                 "ltxk_conv3d_k3_bf16: misaligned pointer");
+  const long long M = (long long)a->B * a->D * a->H * a->W;
+  LTXK_CHECK_ARG(M < (1ll << 31), "ltxk_conv3d_k3_bf16: volume too large");
+  ConvParams p;
+  p.x = (const bf16*)a->x; p.w = (const bf16*)a->w; p.bias = (const bf16*)a->bias; p.out = (bf16*)a->out;
+  p.resid = (const bf16*)a->resid; p.zero = (const bf16*)a->zero_page;
+  p.B = a->B; p.D = a->D; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
+  p.causal = a->causal; p.pad_mode = a->pad_mode; p.M = (int)M; p.cpb = a->Cin / 64; p.RT = p.CT = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool res = a->resid != nullptr;
+  if (a->Cout <= 128) {       // 256x128 tile: no wasted MFMA columns on the 128-channel stage
+    return res ? conv_launch<4, 2, true>(p, st) : conv_launch<4, 2, false>(p, st);
+  }
+  return res ? conv_launch<5, 4, true>(p, st) : conv_launch<5, 4, false>(p, st);
+}

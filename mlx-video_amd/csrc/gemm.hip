@@ -6,6 +6,8 @@
 
 namespace ltxk {
 
+constexpr int GEMM_BN = 256;
+
 struct GemmParams {
   const bf16* A;
   const bf16* W;
@@ -21,7 +23,8 @@ struct GemmParams {
 
 template <int TT, int EPI, bool TRANS>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
-  using G = GemmGeom<TT>;
+  using G = GemmGeom<TT, 4>;
+  constexpr int GEMM_W_STAGE_BYTES = G::W_STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
       s2 = s2 >= 3 ? s2 - 3 : s2;
       issue(kt + 2, s2);
     }
-    mma_stage<TT, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
+    mma_stage<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
     s = s + 1 == 3 ? 0 : s + 1;
   }
 
@@ -165,17 +168,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 
 template <int TT, int EPI, bool TRANS>
 static int launch(const GemmParams& p, hipStream_t stream) {
-  using G = GemmGeom<TT>;
+  using G = GemmGeom<TT, 4>;
   auto kern = gemm_bf16_kernel<TT, EPI, TRANS>;
-  static thread_local bool attr_set = false;
-  if (!attr_set) {
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::LDS_BYTES);
     if (e != hipSuccess) {
       ltxk_set_error("ltxk_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
       return LTXK_ELAUNCH;
     }
-    attr_set = true;
+    attr_dev = dev;
   }
   hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
   LTXK_CHECK_LAUNCH("ltxk_gemm_bf16");

@@ -2,8 +2,10 @@
 //
 //   C[m,n] = sum_k A[m,k] * W[n,k]          A rows and W rows are both k-contiguous bf16
 //
-// Geometry (gfx950, wave64): one workgroup = 8 waves = 2 (rows) x 4 (cols); tile BM x 256 x 64
-// with BM = 32*TT; per wave TT x 4 MFMA tiles of v_mfma_f32_16x16x32_bf16.
+// Geometry (gfx950, wave64): one workgroup = 8 waves = WM (rows) x WN (cols), WM*WN = 8;
+// tile BM x BN x 64 with BM = 16*TT*WM, BN = 64*WN; per wave TT x 4 MFMA tiles of
+// v_mfma_f32_16x16x32_bf16.  (TT=5, WN=4): 160x256, the Linear layers at M=2560;
+// (TT=4, WN=2): 256x128, the 128-channel convolutions.
 // Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 3-deep LDS ring; one
 // raw s_barrier per K-step, counted vmcnt so that two K-steps stay in flight across it.
 // LDS image: 128-byte rows ([row][64 bf16]) with the 16-byte chunk index XOR-swizzled by
@@ -15,21 +17,25 @@
 
 namespace ltxk {
 
-constexpr int GEMM_BN = 256;
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_THREADS = 512;
-constexpr int GEMM_W_STAGE_BYTES = GEMM_BN * GEMM_BK * 2;  // 32 KiB
 
-template <int TT>
+template <int TT, int WN>
 struct GemmGeom {
-  static constexpr int BM = 32 * TT;
-  static constexpr int A_PIECES = BM / 8;          // 1 KiB pieces (8 rows x 128 B)
+  static constexpr int WM = 8 / WN;
+  static constexpr int BM = 16 * TT * WM;
+  static constexpr int BN = 64 * WN;
+  static constexpr int W_PIECES = BN / 8;          // 1 KiB pieces (8 rows x 128 B)
+  static constexpr int W_PER_WAVE = W_PIECES / 8;
+  static constexpr int W_STAGE_BYTES = BN * GEMM_BK * 2;
+  static constexpr int A_PIECES = BM / 8;
   static constexpr int A_BASE = A_PIECES / 8;      // pieces per wave (floor)
   static constexpr int A_REM = A_PIECES % 8;       // first A_REM waves take one more
   static constexpr int MAXA = A_BASE + (A_REM ? 1 : 0);
-  static constexpr int STAGE_BYTES = GEMM_W_STAGE_BYTES + BM * GEMM_BK * 2;
+  static constexpr int STAGE_BYTES = W_STAGE_BYTES + BM * GEMM_BK * 2;
   static constexpr int STAGES = 3;
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
@@ -59,6 +65,8 @@ __device__ __forceinline__ void map_tile(int bid, int RT, int CT, int& rt, int& 
 __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
   switch (keep) {
     case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
@@ -69,11 +77,12 @@ __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
 // One K-step of MFMAs for this wave out of LDS stage `st`.
 // SWAP=false: acc tile = D[n (4 regs)][tok (lane&15)]  (W is the MFMA A operand)
 // SWAP=true : acc tile = D[tok (4 regs)][n (lane&15)]
-template <int TT, bool SWAP>
+template <int TT, int WN, bool SWAP>
 __device__ __forceinline__ void mma_stage(const char* st, int wm, int wn, int lane,
                                           f32x4 (&acc)[TT][4]) {
+  using G = GemmGeom<TT, WN>;
   const char* wb = st + (wn * 64) * 128;
-  const char* ab = st + GEMM_W_STAGE_BYTES + (wm * TT * 16) * 128;
+  const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128;
   const int rowoff = (lane & 15) * 128;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {

@@ -1,0 +1,193 @@
+"""Video-VAE parity: HIP kernels through the C ABI vs the CPU oracle (oracle/vae.py, bf16-storage
+policy) on seeded inputs.  Index maps (patchify/unpatchify/d2s/s2d, uint8 layout) are bit-exact;
+convolutions differ only by fp32 accumulation order (<= 1 bf16 ulp on a small fraction); full
+decode/encode: stated tolerance rel-L2 <= 2e-2 (40+ bf16 layers)."""
+import pytest
+import torch
+
+from oracle import dit as O
+from oracle import vae as OV
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cl(x):   # (B,C,D,H,W) -> channels-last (B,D,H,W,C)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def cf(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,causal,reflect,shape", [
+    (128, 128, False, True, (1, 3, 5, 6)), (128, 128, True, False, (2, 2, 4, 4)), (64, 256, True, False, (1, 4, 6, 5)),
+    (256, 48, False, True, (1, 2, 8, 8)), (1024, 1024, False, True, (1, 2, 4, 4)), (128, 1024, False, True, (1, 1, 2, 2)),
+    (512, 128, True, True, (1, 5, 3, 7))])
+def test_conv3d(dev, cin, cout, causal, reflect, shape):
+    from mlx_video_amd import video_vae as V
+    b, d, h, w = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(b, cin, d, h, w, generator=g).to(BF)
+    wt = (torch.randn(cout, 3, 3, 3, cin, generator=g) / (27 * cin) ** 0.5).to(BF)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(BF)
+    res = torch.randn(b, cout, d, h, w, generator=g).to(BF)
+    ref = OV.causal_conv3d(x.float(), wt, bias, O.BF16, causal, reflect)
+    out = V.conv3d(cl(x).to(dev), wt.to(dev), bias.to(dev), causal, V.PAD_REFLECT if reflect else V.PAD_ZEROS)
+    out_r = V.conv3d(cl(x).to(dev), wt.to(dev), bias.to(dev), causal, V.PAD_REFLECT if reflect else V.PAD_ZEROS,
+                     resid=cl(res).to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(cf(out), ref) < 3e-3
+    assert rel_l2(cf(out_r), O.BF16.r(ref + res.float())) < 3e-3
+
+
+@pytest.mark.parametrize("C", [128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("mod", [False, True])
+def test_pixelnorm_act(dev, C, mod):
+    from mlx_video_amd import video_vae as V
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(2, C, 2, 3, 5, generator=g) * 2).to(BF)
+    p = O.BF16
+    ref = OV.pixel_norm(x.float(), p, 1e-8)
+    sc = sh = None
+    if mod:
+        sc = torch.randn(2, C, generator=g).to(BF)
+        sh = torch.randn(2, C, generator=g).to(BF)
+        ref = OV._mod(ref, sc.float().reshape(2, C, 1, 1, 1), sh.float().reshape(2, C, 1, 1, 1), p)
+    ref = O.silu(ref, p)
+    out = V.pixelnorm_act(cl(x).to(dev), 1e-8, True, sc.to(dev) if mod else None, sh.to(dev) if mod else None)
+    torch.cuda.synchronize()
+    assert rel_l2(cf(out), ref) < 3e-3
+
+
+def test_d2s_add_exact(dev):
+    from mlx_video_amd import video_vae as V
+    g = torch.Generator().manual_seed(1)
+    B, Ci, D, H, W = 1, 64, 3, 2, 3
+    Co = Ci // 2
+    x = torch.randn(B, Ci, D, H, W, generator=g).to(BF)
+    cv = torch.randn(B, Co * 8, D, H, W, generator=g).to(BF)
+    ref = O.BF16.r(OV.depth_to_space(cv.float(), 2, 2, 2)[:, :, 1:] +
+                   OV.depth_to_space(x.float(), 2, 2, 2).repeat(1, 4, 1, 1, 1)[:, :, 1:])
+    out = V.d2s_add(cl(cv).to(dev), cl(x).to(dev))
+    torch.cuda.synchronize()
+    assert out.shape == (B, 2 * D - 1, 2 * H, 2 * W, Co)
+    assert torch.equal(cf(out).float().cpu(), ref)
+
+
+def test_patchify_unpatchify_uint8_exact(dev):
+    from mlx_video_amd import _lib
+    from mlx_video_amd import video_vae as V
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    vid = (torch.rand(1, 3, 2, 8, 12, generator=g) * 2.4 - 1.2).to(BF)
+    ref_p = OV.patchify(vid.float(), 4)                                  # (1,48,2,2,3)
+    out = torch.empty(1, 2, 2, 3, 64, dtype=BF, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    vd = vid.to(dev)
+    assert lib.ltxk_patchify_cl(vd.data_ptr(), out.data_ptr(), 1, 3, 2, 8, 12, 4, 64, st) == 0
+    back = torch.empty(1, 3, 2, 8, 12, dtype=BF, device=dev)
+    o48 = out[..., :48].contiguous()
+    assert lib.ltxk_unpatchify_cf(o48.data_ptr(), back.data_ptr(), 1, 2, 2, 3, 3, 4, st) == 0
+    u8 = V.to_uint8_frames(vid.to(dev))
+    torch.cuda.synchronize()
+    assert torch.equal(cf(out[..., :48]).float().cpu(), ref_p) and float(out[..., 48:].abs().max()) == 0.0
+    assert torch.equal(back.cpu(), vid)                                   # unpatchify(patchify(x)) == x
+    assert torch.equal(OV.unpatchify(ref_p, 4), vid.float())
+    assert torch.equal(u8[0].cpu(), OV.to_uint8(vid[0].float(), O.BF16))
+
+
+@pytest.mark.parametrize("stride,cx,cc", [((1, 2, 2), 128, 64), ((2, 1, 1), 64, 64), ((2, 2, 2), 64, 16)])
+def test_s2d_skip(dev, stride, cx, cc):
+    from mlx_video_amd import _lib
+    lib = _lib.load()
+    st_, sh, sw = stride
+    g = torch.Generator().manual_seed(3)
+    B, Dp, Hp, Wp = 1, 4, 4, 6
+    x = torch.randn(B, cx, Dp, Hp, Wp, generator=g).to(BF)
+    cv = torch.randn(B, cc, Dp, Hp, Wp, generator=g).to(BF)
+    mult = st_ * sh * sw
+    co = cc * mult
+    xin = OV.space_to_depth(x.float(), st_, sh, sw)
+    gsz = xin.shape[1] // co
+    xin = O.BF16.r(xin.reshape(B, co, gsz, *xin.shape[2:]).mean(dim=2))
+    ref = O.BF16.r(OV.space_to_depth(cv.float(), st_, sh, sw) + xin)
+    out = torch.empty(B, Dp // st_, Hp // sh, Wp // sw, co, dtype=BF, device=dev)
+    cvd, xd = cl(cv).to(dev), cl(x).to(dev)          # keep alive until the kernel has run
+    rc = lib.ltxk_s2d_skip(cvd.data_ptr(), xd.data_ptr(), out.data_ptr(), B, Dp, Hp, Wp, cc, cx,
+                           st_, sh, sw, cx // cc, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert rel_l2(cf(out), ref) < 2e-3
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_decode_small(dev, causal):
+    from mlx_video_amd.video_vae import LTX2VideoDecoder
+    W = OV.make_decoder_weights(seed=21, layers_per_block=2)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, num_layers_per_block=2)
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(1, 128, 2, 3, 4, generator=g).to(BF)
+    ref = OV.vae_decode(lat.float(), W, O.BF16, causal=causal, layers_per_block=2)
+    out = dec(lat.to(dev), causal=causal)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 9, 96, 128) and ref.shape == out.shape
+    assert rel_l2(out, ref) < 2e-2
+    assert rel_l2(out, OV.vae_decode(lat.float(), W, O.F32, causal=causal, layers_per_block=2)) < 5e-2
+
+
+def test_decode_timestep_conditioned(dev):
+    from mlx_video_amd.video_vae import LTX2VideoDecoder
+    W = OV.make_decoder_weights(seed=22, layers_per_block=1, timestep_conditioning=True)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, timestep_conditioning=True, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 128, 1, 2, 2, generator=g).to(BF)
+    noise = torch.randn(1, 128, 1, 2, 2, generator=g).to(BF)
+    ref = OV.vae_decode(lat.float(), W, O.BF16, timestep=0.05, noise=noise.float(), layers_per_block=1)
+    out = dec(lat.to(dev), noise=noise.to(dev))
+    torch.cuda.synchronize()
+    assert rel_l2(out, ref) < 2e-2
+    with pytest.raises(ValueError, match="noise"):
+        dec(lat.to(dev))
+
+
+def test_decode_tiled_matches_oracle_tiling(dev):
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig
+    W = OV.make_decoder_weights(seed=23, layers_per_block=1)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(1, 128, 4, 3, 4, generator=g).to(BF)
+    emitted = []
+    out = dec.decode_tiled(lat.to(dev), TilingConfig(spatial_config=TilingConfig.spatial_only(64, 32).spatial_config,
+                                                     temporal_config=TilingConfig.temporal_only(16, 8).temporal_config),
+                           on_frames_ready=lambda fr, i: emitted.append((i, fr.shape[2])))
+    torch.cuda.synchronize()
+    ref = OV.decode_with_tiling(lambda z: OV.vae_decode(z.float(), W, O.BF16, layers_per_block=1), lat, 64, 32, 16, 8, O.BF16)
+    assert out.shape == (1, 3, 25, 96, 128)
+    assert rel_l2(out, ref) < 2e-2
+    cov = set()
+    for i, n in emitted:
+        cov |= set(range(i, i + n))
+    assert cov == set(range(25))                      # every frame emitted exactly once overall
+
+
+def test_encode_small(dev):
+    from mlx_video_amd.video_vae import VideoEncoder
+    blocks = [("res_x", 1), ("compress_space_res", (1, 2, 2)), ("res_x", 1), ("compress_time_res", (2, 1, 1)),
+              ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1)]
+    W = OV.make_encoder_weights(seed=24, blocks=blocks)
+    enc = VideoEncoder({k: v.to(dev) for k, v in W.items()}, encoder_blocks=blocks)
+    g = torch.Generator().manual_seed(7)
+    vid = (torch.rand(1, 3, 9, 64, 96, generator=g) * 2 - 1).to(BF)
+    ref = OV.vae_encode(vid.float(), W, O.BF16, blocks)
+    out = enc(vid.to(dev))
+    torch.cuda.synchronize()
+    assert out.shape == (1, 128, 2, 2, 3) and ref.shape == out.shape
+    assert rel_l2(out, ref) < 2e-2
+    with pytest.raises(ValueError, match="1 \\+ 8"):
+        enc(vid[:, :, :8].to(dev))
