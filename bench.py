@@ -104,7 +104,7 @@ def main() -> None:
     model.cache_context = args.cache_context
     Fl, Hl, Wl = 1 + (args.frames - 1) // 8, args.height // 32, args.width // 32
     N = Fl * Hl * Wl
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    g = torch.Generator(device=dev).manual_seed(42 + (rank if args.shard == "seeds" else rank // 2))
     latents = torch.randn((1, 128, Fl, Hl, Wl), generator=g, device=dev).to(torch.bfloat16)
     g2 = torch.Generator(device=dev).manual_seed(43)
     ctx_pos = torch.randn((1, 1024, 3840), generator=g2, device=dev).to(torch.bfloat16)
