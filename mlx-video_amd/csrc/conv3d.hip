@@ -41,44 +41,51 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     r = r < p.Cout ? r : p.Cout - 1;
     wptr[i] = p.w + (size_t)r * K + chunk * 8;
   }
+  // uniform piece count per wave (see gemm.hip): waves past A_REM re-issue their last A piece
   const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
   const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
-  int vb[G::MAXA], vd[G::MAXA], vh[G::MAXA], vw[G::MAXA];
+  int vb[G::MAXA], vd[G::MAXA], vh[G::MAXA], vw[G::MAXA], adst[G::MAXA];
 #pragma unroll
   for (int i = 0; i < G::MAXA; ++i) {
-    int r = m0 + (a0 + i) * 8 + lrow;
+    const int pi = nA > 0 ? a0 + (i < nA ? i : nA - 1) : G::A_PIECES - 1;   // no own piece: re-issue the tile's last one
+    int r = m0 + pi * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
     vw[i] = r % p.W; r /= p.W;
     vh[i] = r % p.H; r /= p.H;
     vd[i] = r % p.D; vb[i] = r / p.D;
+    adst[i] = G::W_STAGE_BYTES + (pi < G::A_PIECES ? pi : G::A_PIECES - 1) * 1024;
   }
-  const int per_stage = G::W_PER_WAVE + nA;
+  constexpr int PER_STAGE = G::W_PER_WAVE + G::MAXA;
+  static_assert(PER_STAGE <= 7, "vmcnt immediates assume <= 7 pieces per stage");
   const bf16* zsrc = p.zero + chunk * 8;
 
-  auto issue = [&](int kt, int s) {
+  // i-th LDS-DMA piece of this wave for K-step (tap = (kd,kh,kw), channel block cb) into ring slot s
+  auto issue_piece = [&](int i, int kt, int kd, int kh, int kw, int cb, int s) {
     char* base = smem + s * G::STAGE_BYTES;
+    if (i < G::W_PER_WAVE) {
+      glds16(wptr[i < G::W_PER_WAVE ? i : 0] + kt * GEMM_BK, base + (wave * G::W_PER_WAVE + i) * 1024);
+    } else if (i < PER_STAGE) {
+      const int j = i - G::W_PER_WAVE < G::MAXA ? i - G::W_PER_WAVE : 0;
+      int d = vd[j] + kd - (p.causal ? 2 : 1);
+      d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
+      int h = vh[j] + kh - 1, w = vw[j] + kw - 1;
+      bool zero = false;
+      if (p.pad_mode == LTXK_PAD_REFLECT) {
+        h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
+        w = w < 0 ? 1 : (w >= p.W ? p.W - 2 : w);
+      } else {
+        zero = (h < 0) | (h >= p.H) | (w < 0) | (w >= p.W);
+      }
+      const size_t vox = (((size_t)vb[j] * p.D + d) * p.H + h) * p.W + w;
+      const bf16* src = zero ? zsrc : p.x + vox * p.Cin + cb * 64 + chunk * 8;
+      glds16(src, base + adst[j]);
+    }
+  };
+  auto issue_all = [&](int kt, int s) {
     const int tap = kt / p.cpb, cb = kt - tap * p.cpb;
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
 #pragma unroll
-    for (int i = 0; i < G::W_PER_WAVE; ++i)
-      glds16(wptr[i] + kt * GEMM_BK, base + (wave * G::W_PER_WAVE + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < G::MAXA; ++i)
-      if (i < nA) {
-        int d = vd[i] + kd - (p.causal ? 2 : 1);
-        d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
-        int h = vh[i] + kh - 1, w = vw[i] + kw - 1;
-        bool zero = false;
-        if (p.pad_mode == LTXK_PAD_REFLECT) {
-          h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
-          w = w < 0 ? 1 : (w >= p.W ? p.W - 2 : w);
-        } else {
-          zero = (h < 0) | (h >= p.H) | (w < 0) | (w >= p.W);
-        }
-        const size_t vox = (((size_t)vb[i] * p.D + d) * p.H + h) * p.W + w;
-        const bf16* src = zero ? zsrc : p.x + vox * p.Cin + cb * 64 + chunk * 8;
-        glds16(src, base + G::W_STAGE_BYTES + (a0 + i) * 1024);
-      }
+    for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, kt, kd, kh, kw, cb, s);
   };
 
   f32x4 acc[TT][4];
@@ -88,19 +95,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = 27 * p.cpb;
-  issue(0, 0);
-  issue(1, 1);
+  issue_all(0, 0);
+  issue_all(1, 1);
   int s = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    wait_stage_and_barrier(kt + 1 < nk ? per_stage : 0);
-    if (kt + 2 < nk) {
-      int s2 = s + 2;
-      s2 = s2 >= 3 ? s2 - 3 : s2;
-      issue(kt + 2, s2);
-    }
-    mma_stage<TT, WN, false>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
+    wait_stage_and_barrier(PER_STAGE);
+    int s2 = s + 2;
+    s2 = s2 >= 3 ? s2 - 3 : s2;
+    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+    const int tap = kt2 / p.cpb, cb = kt2 - tap * p.cpb;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    mma_stage_pipelined<TT, WN, false>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
+                                       [&](int i) { issue_piece(i, kt2, kd, kh, kw, cb, s2); });
     s = s + 1 == 3 ? 0 : s + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j
   const int nq = (lane >> 4) * 4;

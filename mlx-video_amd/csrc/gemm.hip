@@ -45,25 +45,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     r = r < p.N ? r : p.N - 1;
     wptr[i] = p.W + (size_t)r * p.K + chunk * 8;
   }
+  // Every wave issues exactly 4 W pieces + MAXA A pieces per stage, so one constant vmcnt retires a
+  // stage.  A_PIECES is not a multiple of 8 (20 at BM=160): waves past A_REM own one piece fewer and
+  // re-issue their last piece (same source, same LDS bytes: benign) to keep the count uniform.
   const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
   const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
   const bf16* aptr[G::MAXA];
+  int adst[G::MAXA];
 #pragma unroll
   for (int i = 0; i < G::MAXA; ++i) {
-    int r = m0 + (a0 + i) * 8 + lrow;
+    const int pi = nA > 0 ? a0 + (i < nA ? i : nA - 1) : G::A_PIECES - 1;   // no own piece: re-issue the tile's last one
+    int r = m0 + pi * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
     aptr[i] = p.A + (size_t)r * p.lda + chunk * 8;
+    adst[i] = GEMM_W_STAGE_BYTES + (pi < G::A_PIECES ? pi : G::A_PIECES - 1) * 1024;
   }
-  const int per_stage = 4 + nA;
+  constexpr int PER_STAGE = 4 + G::MAXA;
+  static_assert(PER_STAGE <= 7, "vmcnt immediates below assume <= 7 pieces per stage");
 
-  auto issue = [&](int kt, int s) {
+  // i-th LDS-DMA piece of this wave for K-step kt into ring slot s (pieces 0..3 = W, 4.. = A)
+  auto issue_piece = [&](int i, int kt, int s) {
     char* base = smem + s * G::STAGE_BYTES;
     const int ko = kt * GEMM_BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(wptr[i] + ko, base + (wave * 4 + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < G::MAXA; ++i)
-      if (i < nA) glds16(aptr[i] + ko, base + GEMM_W_STAGE_BYTES + (a0 + i) * 1024);
+    if (i < 4) {
+      glds16(wptr[i] + ko, base + (wave * 4 + i) * 1024);
+    } else if (i < PER_STAGE) {
+      glds16(aptr[i - 4 < G::MAXA ? i - 4 : 0] + ko, base + adst[i - 4 < G::MAXA ? i - 4 : 0]);
+    }
   };
 
   f32x4 acc[TT][4];
@@ -73,19 +81,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GEMM_BK;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
   int s = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    wait_stage_and_barrier(kt + 1 < nk ? per_stage : 0);
-    if (kt + 2 < nk) {
-      int s2 = s + 2;
-      s2 = s2 >= 3 ? s2 - 3 : s2;
-      issue(kt + 2, s2);
-    }
-    mma_stage<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc);
+    // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
+    wait_stage_and_barrier(PER_STAGE);
+    int s2 = s + 2;
+    s2 = s2 >= 3 ? s2 - 3 : s2;
+    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;     // tail: harmless re-load of the last stage into a free slot
+    mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
+                                      [&](int i) { issue_piece(i, kt2, s2); });
     s = s + 1 == 3 ? 0 : s + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue ----
   if constexpr (!TRANS) {

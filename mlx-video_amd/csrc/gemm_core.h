@@ -38,9 +38,20 @@ struct GemmGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
+// LDS-DMA of one 1-KiB piece: lane i's 16 bytes at gsrc land at lds_dst + 16*i (lds_dst wave-uniform).
+// Issued as inline asm on purpose: hipcc (ROCm 7.2) models the builtin as a FLAT access that may
+// touch LDS, which degrades every later ds_read wait in the loop to `s_waitcnt lgkmcnt(0)` — the
+// fragment prefetch two MFMA groups ahead would then be drained at each use.  Hidden in asm, the
+// compiler emits counted lgkmcnt waits for its ds_reads; the DMA itself is retired by the counted
+// vmcnt in wait_stage_and_barrier().  M0 (the DMA's LDS base) is written and restored inside the
+// one statement that uses it.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
 }
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
@@ -98,6 +109,56 @@ __device__ __forceinline__ void mma_stage(const char* st, int wm, int wn, int la
       for (int nt = 0; nt < 4; ++nt)
         acc[tt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], wf[nt], acc[tt][nt], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[tt], acc[tt][nt], 0, 0, 0);
+  }
+}
+
+// Software-pipelined K-step: the 2*TT MFMA groups (4 MFMAs each: one A-row fragment x 4 W
+// fragments) run in a fixed order pinned by sched_barrier; fragment ds_read_b128s are issued two
+// groups ahead of their use, and this wave's LDS-DMA pieces of the stage two K-steps ahead are
+// sprinkled one (or PPG) per group instead of being issued as a burst in front of the MFMAs — the
+// DMA issue cost (~60-180 cycles per 1-KiB piece) then hides under the matrix pipe.
+// issue(i): launch this wave's i-th LDS-DMA piece of the prefetched stage (no-op for i >= count).
+template <int TT, int WN, bool SWAP, class IssueFn>
+__device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int wn, int lane,
+                                                    f32x4 (&acc)[TT][4], IssueFn&& issue) {
+  using G = GemmGeom<TT, WN>;
+  constexpr int NG = 2 * TT;                                   // MFMA groups per K-step
+  constexpr int MAXP = G::W_PER_WAVE + G::MAXA;                // LDS-DMA pieces per wave per stage
+  constexpr int PPG = (MAXP + NG - 1) / NG;
+  const char* wb = st + (wn * 64) * 128 + (lane & 15) * 128;
+  const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128 + (lane & 15) * 128;
+  const int koff0 = (((lane >> 4)) ^ (lane & 7)) << 4;
+  const int koff1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
+  bf16x8 wf[2][4], af[2][TT];
+  // flat read order: W0[0..3], A0[0..TT-1], W1[0..3], A1[0..TT-1]
+  auto rd = [&](int idx) {
+    // idx is a compile-time constant after unrolling
+    const int ks = idx / (4 + TT), r = idx % (4 + TT);
+    const int ko = ks ? koff1 : koff0;
+    if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
+    else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
+  };
+  constexpr int TOTAL = 2 * (4 + TT);
+  auto need = [](int g) { return (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
+  int issued = 0;
+#pragma unroll
+  for (int i = 0; i < TOTAL; ++i)
+    if (i < need(1 < NG ? 1 : 0)) { rd(i); issued = i + 1; }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int target = need(g + 2 < NG ? g + 2 : NG - 1);
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i)
+      if (i >= issued && i < target) rd(i);
+    issued = target > issued ? target : issued;
+#pragma unroll
+    for (int q = 0; q < PPG; ++q) issue(g * PPG + q);
+    const int ks = g / TT, tt = g % TT;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      acc[tt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][tt], wf[ks][nt], acc[tt][nt], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], af[ks][tt], acc[tt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
