@@ -48,12 +48,13 @@ __device__ __forceinline__ float rbf(float x) {
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // nn.gelu_approx: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1)
-  const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+  // tanh(u) = 1 - 2/(exp(2u)+1); v_exp_f32 + v_rcp_f32 (1 ulp each, far below the bf16 the result
+  // is rounded to) instead of an IEEE division: the epilogue of the FF1 GEMM is VALU-bound otherwise.
+  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.885390081777927f * u) + 1.0f);
   return 0.5f * x * (1.0f + t);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -44,48 +44,77 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   // uniform piece count per wave (see gemm.hip): waves past A_REM re-issue their last A piece
   const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
   const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
-  int vb[G::MAXA], vd[G::MAXA], vh[G::MAXA], vw[G::MAXA], adst[G::MAXA];
+  // The halo is separable: byte offset of (voxel, tap) = od[kd] + oh[kh] + ow[kw].  The nine per-piece
+  // partial offsets are computed once; per tap the source address costs a few selects and adds instead
+  // of re-deriving clamp/reflect/zero for every 64-channel K-step (the 128-channel stage would otherwise
+  // be bound by address VALU, not by MFMA).  Offsets are 32-bit (volume < 4 GiB, checked on the host).
+  unsigned od[G::MAXA][3], oh[G::MAXA][3], ow[G::MAXA][3];
+  unsigned zbits[G::MAXA];
+  int adst[G::MAXA];
+  const unsigned rowB = (unsigned)p.Cin * 2u;
 #pragma unroll
   for (int i = 0; i < G::MAXA; ++i) {
     const int pi = nA > 0 ? a0 + (i < nA ? i : nA - 1) : G::A_PIECES - 1;   // no own piece: re-issue the tile's last one
     int r = m0 + pi * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
-    vw[i] = r % p.W; r /= p.W;
-    vh[i] = r % p.H; r /= p.H;
-    vd[i] = r % p.D; vb[i] = r / p.D;
+    const int vw = r % p.W; r /= p.W;
+    const int vh = r % p.H; r /= p.H;
+    const int vd = r % p.D;
+    const int vb = r / p.D;
     adst[i] = G::W_STAGE_BYTES + (pi < G::A_PIECES ? pi : G::A_PIECES - 1) * 1024;
+    unsigned zb = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int d = vd + k - (p.causal ? 2 : 1);
+      d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
+      int h = vh + k - 1, w = vw + k - 1;
+      if (p.pad_mode == LTXK_PAD_REFLECT) {
+        h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
+        w = w < 0 ? 1 : (w >= p.W ? p.W - 2 : w);
+      } else {
+        if (h < 0 || h >= p.H) { zb |= 1u << k; h = 0; }
+        if (w < 0 || w >= p.W) { zb |= 8u << k; w = 0; }
+      }
+      od[i][k] = (unsigned)((vb * p.D + d) * p.H) * (unsigned)p.W * rowB;
+      oh[i][k] = (unsigned)(h * p.W) * rowB;
+      ow[i][k] = (unsigned)w * rowB + (unsigned)chunk * 16u;
+    }
+    zbits[i] = zb;
   }
   constexpr int PER_STAGE = G::W_PER_WAVE + G::MAXA;
   static_assert(PER_STAGE <= 7, "vmcnt immediates assume <= 7 pieces per stage");
-  const bf16* zsrc = p.zero + chunk * 8;
+  const char* zsrc = (const char*)p.zero + chunk * 16;
+  const char* xb = (const char*)p.x;
 
-  // i-th LDS-DMA piece of this wave for K-step (tap = (kd,kh,kw), channel block cb) into ring slot s
-  auto issue_piece = [&](int i, int kt, int kd, int kh, int kw, int cb, int s) {
+  // per-tap source state of the prefetch stream
+  unsigned off_tap[G::MAXA];
+  bool ztap[G::MAXA];
+  auto set_tap = [&](int tap) __attribute__((always_inline)) {
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    // 3-way selects as scalar bit masks (a ?: chain is turned into a scratch-memory table lookup by hipcc)
+    const unsigned d0 = kd == 0 ? ~0u : 0u, d1 = kd == 1 ? ~0u : 0u, d2 = kd == 2 ? ~0u : 0u;
+    const unsigned h0 = kh == 0 ? ~0u : 0u, h1 = kh == 1 ? ~0u : 0u, h2 = kh == 2 ? ~0u : 0u;
+    const unsigned w0 = kw == 0 ? ~0u : 0u, w1 = kw == 1 ? ~0u : 0u, w2 = kw == 2 ? ~0u : 0u;
+#pragma unroll
+    for (int j = 0; j < G::MAXA; ++j) {
+      const unsigned a = (od[j][0] & d0) | (od[j][1] & d1) | (od[j][2] & d2);
+      const unsigned b = (oh[j][0] & h0) | (oh[j][1] & h1) | (oh[j][2] & h2);
+      const unsigned c = (ow[j][0] & w0) | (ow[j][1] & w1) | (ow[j][2] & w2);
+      off_tap[j] = a + b + c;
+      ztap[j] = ((zbits[j] >> kh) & 1u) | ((zbits[j] >> (3 + kw)) & 1u);
+    }
+  };
+
+  // i-th LDS-DMA piece of this wave for K-step kt (channel block cb of the current tap) into ring slot s
+  auto issue_piece = [&](int i, int kt, int cb, int s) __attribute__((always_inline)) {
     char* base = smem + s * G::STAGE_BYTES;
     if (i < G::W_PER_WAVE) {
       glds16(wptr[i < G::W_PER_WAVE ? i : 0] + kt * GEMM_BK, base + (wave * G::W_PER_WAVE + i) * 1024);
     } else if (i < PER_STAGE) {
       const int j = i - G::W_PER_WAVE < G::MAXA ? i - G::W_PER_WAVE : 0;
-      int d = vd[j] + kd - (p.causal ? 2 : 1);
-      d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
-      int h = vh[j] + kh - 1, w = vw[j] + kw - 1;
-      bool zero = false;
-      if (p.pad_mode == LTXK_PAD_REFLECT) {
-        h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
-        w = w < 0 ? 1 : (w >= p.W ? p.W - 2 : w);
-      } else {
-        zero = (h < 0) | (h >= p.H) | (w < 0) | (w >= p.W);
-      }
-      const size_t vox = (((size_t)vb[j] * p.D + d) * p.H + h) * p.W + w;
-      const bf16* src = zero ? zsrc : p.x + vox * p.Cin + cb * 64 + chunk * 8;
+      const char* src = ztap[j] ? zsrc : xb + (size_t)(off_tap[j] + (unsigned)cb * 128u);
       glds16(src, base + adst[j]);
     }
-  };
-  auto issue_all = [&](int kt, int s) {
-    const int tap = kt / p.cpb, cb = kt - tap * p.cpb;
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-#pragma unroll
-    for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, kt, kd, kh, kw, cb, s);
   };
 
   f32x4 acc[TT][4];
@@ -95,20 +124,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = 27 * p.cpb;
-  issue_all(0, 0);
-  issue_all(1, 1);
+  // prologue: stages 0 and 1 (both in tap 0 unless cpb == 1)
+  int ptap = 0, pcb = 0;                 // (tap, channel block) of the prefetch stream
+  set_tap(0);
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0, 0);
+  pcb = 1;
+  if (pcb == p.cpb) { pcb = 0; ptap = 1; set_tap(1); }
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 1, pcb, 1);
   int s = 0;
+  MmaPipe<TT, WN, false> pipe;
+  pipe.init();
   for (int kt = 0; kt < nk; ++kt) {
     wait_stage_and_barrier(PER_STAGE);
     int s2 = s + 2;
     s2 = s2 >= 3 ? s2 - 3 : s2;
-    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
-    const int tap = kt2 / p.cpb, cb = kt2 - tap * p.cpb;
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    mma_stage_pipelined<TT, WN, false>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
-                                       [&](int i) { issue_piece(i, kt2, kd, kh, kw, cb, s2); });
+    // advance the prefetch stream to K-step kt+2 (held at the last K-step in the tail: harmless re-load)
+    int kt2 = kt + 2;
+    if (kt2 < nk) {
+      ++pcb;
+      if (pcb == p.cpb) { pcb = 0; ++ptap; set_tap(ptap); }
+    } else {
+      kt2 = nk - 1;
+    }
+    const int cb = pcb;
+    pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, cb, s2); });
     s = s + 1 == 3 ? 0 : s + 1;
   }
+  pipe.finish(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j
@@ -173,7 +217,7 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   LTXK_CHECK_ARG((((uintptr_t)a->x | (uintptr_t)a->w | (uintptr_t)a->zero_page) & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
                  "ltxk_conv3d_k3_bf16: misaligned pointer");
   const long long M = (long long)a->B * a->D * a->H * a->W;
-  LTXK_CHECK_ARG(M < (1ll << 31), "ltxk_conv3d_k3_bf16: volume too large");
+  LTXK_CHECK_ARG(M < (1ll << 31) && M * a->Cin * 2 < (1ll << 32), "ltxk_conv3d_k3_bf16: input volume must be < 4 GiB (32-bit tile offsets)");
   ConvParams p;
   p.x = (const bf16*)a->x; p.w = (const bf16*)a->w; p.bias = (const bf16*)a->bias; p.out = (bf16*)a->out;
   p.resid = (const bf16*)a->resid; p.zero = (const bf16*)a->zero_page;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   static_assert(PER_STAGE <= 7, "vmcnt immediates below assume <= 7 pieces per stage");
 
   // i-th LDS-DMA piece of this wave for K-step kt into ring slot s (pieces 0..3 = W, 4.. = A)
-  auto issue_piece = [&](int i, int kt, int s) {
+  auto issue_piece = [&](int i, int kt, int s) __attribute__((always_inline)) {
     char* base = smem + s * G::STAGE_BYTES;
     const int ko = kt * GEMM_BK;
     if (i < 4) {
@@ -86,15 +86,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
   int s = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
-    wait_stage_and_barrier(PER_STAGE);
-    int s2 = s + 2;
-    s2 = s2 >= 3 ? s2 - 3 : s2;
-    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;     // tail: harmless re-load of the last stage into a free slot
-    mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
-                                      [&](int i) { issue_piece(i, kt2, s2); });
-    s = s + 1 == 3 ? 0 : s + 1;
+  if constexpr (TT >= 2) {
+    MmaPipe<TT, 4, TRANS> pipe;
+    pipe.init();
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
+      wait_stage_and_barrier(PER_STAGE);
+      int s2 = s + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
+      pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+      s = s + 1 == 3 ? 0 : s + 1;
+    }
+    pipe.finish(acc);
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage_and_barrier(PER_STAGE);
+      int s2 = s + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
+                                        [&](int i) { issue_piece(i, kt2, s2); });
+      s = s + 1 == 3 ? 0 : s + 1;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 

@@ -75,13 +75,13 @@ __device__ __forceinline__ void map_tile(int bid, int RT, int CT, int& rt, int& 
 // LDS-DMA instructions (the next K-step's) in flight, then rendezvous.
 __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
   switch (keep) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
+    case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
   }
 }
 
@@ -161,5 +161,87 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+// Rotated software pipeline: like mma_stage_pipelined, but the last two MFMA groups of every
+// K-step are deferred until AFTER the next K-step's barrier (their operands are already in
+// registers), so they execute while the first fragment reads of the new stage are in flight: the
+// LDS cold start after each barrier (all 8 waves reading at once) no longer idles the matrix pipe.
+// Requires TT >= 2 (both deferred groups then share the ks=1 W fragments).
+template <int TT, int WN, bool SWAP>
+struct MmaPipe {
+  using G = GemmGeom<TT, WN>;
+  static constexpr int NG = 2 * TT;
+  static constexpr int MAXP = G::W_PER_WAVE + G::MAXA;
+  static constexpr int PPG = (MAXP + NG - 1) / NG;
+  static constexpr int TOTAL = 2 * (4 + TT);
+  // fragment registers persist across K-steps: after step() wf[1][*], af[1][TT-2], af[1][TT-1] hold the
+  // operands of the two deferred groups; the next step() consumes them before overwriting them.
+  bf16x8 wf[2][4], af[2][TT];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wf[1][i][j] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[1][i][j] = (bf16)0.f;
+  }
+
+  static __device__ __forceinline__ void group(const bf16x8& a, const bf16x8 (&w)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      acc[nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[nt], acc[nt], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], a, acc[nt], 0, 0, 0);
+  }
+
+  template <class IssueFn>
+  __device__ __forceinline__ void step(const char* st, int wm, int wn, int lane, f32x4 (&acc)[TT][4], IssueFn&& issue) {
+    static_assert(TT >= 2, "rotated pipeline needs TT >= 2");
+    const char* wb = st + (wn * 64) * 128 + (lane & 15) * 128;
+    const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128 + (lane & 15) * 128;
+    const int koff0 = (((lane >> 4)) ^ (lane & 7)) << 4;
+    const int koff1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
+    auto rd = [&](int idx) {
+      const int ks = idx / (4 + TT), r = idx % (4 + TT);
+      const int ko = ks ? koff1 : koff0;
+      if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
+      else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
+    };
+    auto need = [](int g) { return (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
+    int issued = 0;
+    // virtual groups -2, -1 = the two groups deferred from the previous K-step
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int target = need(v);           // reads needed by real group v (two groups ahead)
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i)
+        if (i >= issued && i < target) rd(i);
+      issued = target;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q) issue(v * PPG + q);
+      group(af[1][TT - 2 + v], wf[1], acc[TT - 2 + v]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG - 2; ++g) {
+      const int target = need(g + 2);
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i)
+        if (i >= issued && i < target) rd(i);
+      issued = target;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q) issue((g + 2) * PPG + q);
+      group(af[g / TT][g % TT], wf[g / TT], acc[g % TT]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TT][4]) {
+    group(af[1][TT - 2], wf[1], acc[TT - 2]);
+    group(af[1][TT - 1], wf[1], acc[TT - 1]);
+  }
+};
 
 }  // namespace ltxk
