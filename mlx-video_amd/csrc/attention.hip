@@ -15,12 +15,11 @@
 // V is consumed transposed (V^T: [d][key], key-contiguous); the V projection GEMM writes it
 // in that layout directly (ltxk_gemm_bf16 out_tokens_per_batch).
 #include "common.h"
+#include <stdlib.h>
 
 namespace ltxk {
 
 constexpr int FA_QW = 32;         // query rows per wave
-constexpr int FA_WAVES = 4;
-constexpr int FA_BQ = FA_QW * FA_WAVES;   // 128 query rows per workgroup
 constexpr int FA_BK = 64;         // keys per tile
 constexpr int FA_DH = 128;
 constexpr int FA_K_BYTES = FA_BK * FA_DH * 2;    // 16 KiB: [64 keys][256 B]
@@ -43,7 +42,12 @@ __device__ __forceinline__ void fa_glds16(const void* g, void* l) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 2) void flash_attn_kernel(FaParams p) {
+// NW waves per workgroup (4 or 5): 128 or 160 query rows.  Two workgroups per CU are resident
+// (64 KiB LDS each), so the grid should be a whole number of 512-slot rounds: at Tq=1280, B*H=64 the
+// 160-row form gives exactly 512 workgroups where the 128-row form gives 640 (a 25 % second round).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
+  constexpr int FA_BQ = FA_QW * NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -73,18 +77,15 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(FaParams p) {
     char* sk = smem + st * FA_STAGE;
     char* sv = sk + FA_K_BYTES;
     const int key0 = t * FA_BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave * 4 + i;
+    // 16 K pieces + 16 V^T pieces, dealt round-robin over the NW waves (wave-uniform trip count)
+    for (int piece = wave; piece < 16; piece += NW) {
       const int row = piece * 4 + k_lrow;               // key within tile
       int key = key0 + row;
       key = key < p.Tk ? key : p.Tk - 1;
       const int chunk = k_slot ^ (row & 15);
       fa_glds16(kbase + (size_t)key * p.ldk + chunk * 8, sk + piece * 1024);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave * 4 + i;
+    for (int piece = wave; piece < 16; piece += NW) {
       const int d = piece * 8 + v_lrow;
       const int chunk = v_slot ^ ((d >> 1) & 7);
       fa_glds16(vbase + (size_t)d * p.ldvt + key0 + chunk * 8, sv + piece * 1024);
@@ -220,12 +221,22 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev != attr_dev) {
-    hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
     if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
     attr_dev = dev;
   }
-  dim3 grid((Tq + FA_BQ - 1) / FA_BQ, B * H);
-  hipLaunchKernelGGL(flash_attn_kernel, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
+  // The 160-row (5-wave) form removes the partial second round at Tq=1280 but loads the four SIMDs
+  // unevenly (10 waves per CU = 3,3,2,2): measured 8.6 ms/step against 7.6 ms for the 128-row form
+  // (profiles/r01 notes), so the 4-wave form is used unless LTXK_FA_WAVES=5 asks otherwise.
+  static const bool want5 = [] { const char* e = getenv("LTXK_FA_WAVES"); return e && e[0] == '5'; }();
+  if (want5) {
+    dim3 grid((Tq + 159) / 160, B * H);
+    hipLaunchKernelGGL(flash_attn_kernel<5>, grid, dim3(320), FA_LDS, (hipStream_t)stream, p);
+  } else {
+    dim3 grid((Tq + 127) / 128, B * H);
+    hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
+  }
   LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
   return LTXK_OK;
 }
