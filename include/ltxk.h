@@ -49,7 +49,8 @@ enum {
   LTXK_EPI_BIAS_GELU = 1,     /* bf16(gelu_tanh(y))          feed_forward.py:12           */
   LTXK_EPI_BIAS_SILU = 2,     /* bf16(y*sigmoid(y))          adaln.py:136                 */
   LTXK_EPI_BIAS_GATE_RES = 3, /* bf16(res + bf16(y*gate))    transformer.py:254,347       */
-  LTXK_EPI_BIAS_RES = 4       /* bf16(res + y)               transformer.py:257           */
+  LTXK_EPI_BIAS_RES = 4,      /* bf16(res + y)               transformer.py:257           */
+  LTXK_EPI_SCALE_RES = 5      /* bf16(res + bf16(alpha*acc)) LoRA merge W += s*(B@A), lora.py:94-127 */
 };
 
 typedef struct ltxk_gemm_args {
@@ -66,6 +67,7 @@ typedef struct ltxk_gemm_args {
   /* >0: write the output transposed per batch: row m = b*T + t goes to
    * out[(b*N + n)*ldo + t]   (used for V^T so that attention reads V k-contiguous)       */
   int32_t out_tokens_per_batch;
+  float alpha;          /* LTXK_EPI_SCALE_RES only                                        */
 } ltxk_gemm_args;
 
 int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
@@ -161,7 +163,8 @@ typedef struct ltxk_conv3d_args {
   const void* resid;     /* optional (B,D,H,W,Cout): out = bf16(conv + resid) (decoder.py:180) */
   const void* zero_page; /* >= 128 zero bytes in device memory (zero-padding source)       */
   int32_t B, D, H, W, Cin, Cout;
-  int32_t causal;        /* temporal halo: 1 = 2x first frame; 0 = first + last (convolution.py:126-137) */
+  int32_t causal;        /* temporal halo: 1 = 2x first frame; 0 = first + last (convolution.py:126-137);
+                          * 2 = zeros on both sides (plain Conv3d padding=1 of the latent upsampler, upsampler.py:6-62) */
   int32_t pad_mode;      /* spatial halo: LTXK_PAD_ZEROS | LTXK_PAD_REFLECT (convolution.py:143-157) */
 } ltxk_conv3d_args;
 
@@ -208,6 +211,13 @@ int ltxk_patchify_cl(const void* video, void* out, int32_t B, int32_t C, int32_t
 /* video (B,C,F,H,W) bf16 in [-1,1] -> uint8 frames (B,F,H,W,C): generate.py:3894-3898.     */
 int ltxk_to_uint8(const void* x, void* out, int32_t B, int32_t C, int32_t F, int32_t H, int32_t W,
                   void* stream);
+
+/* GroupNorm over (D*H*W, C/G) per (batch, group) in fp32 + affine [+ residual] [+ SiLU]:
+ * upsampler.py:65-98,160-174.  x,out (B,V,C) bf16 channels-last, gamma/beta (C) bf16.
+ *   y = bf16((x-mean)/sqrt(var+eps)*gamma+beta); if resid: y = bf16(y+resid); if silu: bf16(silu(y)) */
+int ltxk_groupnorm_act(const void* x, void* out, const void* gamma, const void* beta, const void* resid,
+                       int32_t B, int64_t V, int32_t C, int32_t G, float eps, int32_t apply_silu,
+                       void* stream);
 
 /* Tiled-decode blending (tiling.py:399-447): acc[b,c,t0+t,h0+y,w0+x] += tile[b,c,t,y,x]*m,
  * wsum[b,t0+t,h0+y,w0+x] += m with m = mt[t]*mh[y]*mw[x]; tile (B,C,Tt,Th,Tw) bf16 of which the

@@ -20,7 +20,7 @@ class GemmArgs(Structure):
         ("resid", c_void_p), ("gate", c_void_p), ("gate_row", c_void_p),
         ("M", c_int32), ("N", c_int32), ("K", c_int32),
         ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32), ("gate_stride", c_int32),
-        ("epilogue", c_int32), ("out_tokens_per_batch", c_int32),
+        ("epilogue", c_int32), ("out_tokens_per_batch", c_int32), ("alpha", c_float),
     ]
 
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "ltxk_patchify_cl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_void_p]),
     "ltxk_to_uint8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_groupnorm_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                     c_float, c_int32, c_void_p]),
     "ltxk_tile_blend_accum": (c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 8 + [c_void_p]),
     "ltxk_tile_blend_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "ltxk_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),

@@ -65,8 +65,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     unsigned zb = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      int d = vd + k - (p.causal ? 2 : 1);
-      d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);            // frame replication
+      int d = vd + k - (p.causal == 1 ? 2 : 1);
+      if (p.causal == 2) {                                 // plain zero padding in time (latent upsampler)
+        if (d < 0 || d >= p.D) { zb |= 64u << k; d = 0; }
+      } else {
+        d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);          // frame replication
+      }
       int h = vh + k - 1, w = vw + k - 1;
       if (p.pad_mode == LTXK_PAD_REFLECT) {
         h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
       const unsigned b = (oh[j][0] & h0) | (oh[j][1] & h1) | (oh[j][2] & h2);
       const unsigned c = (ow[j][0] & w0) | (ow[j][1] & w1) | (ow[j][2] & w2);
       off_tap[j] = a + b + c;
-      ztap[j] = ((zbits[j] >> kh) & 1u) | ((zbits[j] >> (3 + kw)) & 1u);
+      ztap[j] = ((zbits[j] >> kh) & 1u) | ((zbits[j] >> (3 + kw)) & 1u) | ((zbits[j] >> (6 + kd)) & 1u);
     }
   };
 

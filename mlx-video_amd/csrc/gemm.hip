@@ -19,6 +19,7 @@ struct GemmParams {
   int M, N, K, lda, ldo, ldr, gate_stride;
   int RT, CT;
   int T;  // tokens per batch for the transposed output
+  float alpha;
 };
 
 template <int TT, int EPI, bool TRANS>
@@ -150,6 +151,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
           const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
+        } else if constexpr (EPI == LTXK_EPI_SCALE_RES) {
+          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(p.alpha * acc[tt][nt][j]);
         }
         bf16x4 o;
 #pragma unroll
@@ -221,6 +226,7 @@ static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t st
     case LTXK_EPI_BIAS_SILU: return launch<TT, LTXK_EPI_BIAS_SILU, false>(p, stream);
     case LTXK_EPI_BIAS_GATE_RES: return launch<TT, LTXK_EPI_BIAS_GATE_RES, false>(p, stream);
     case LTXK_EPI_BIAS_RES: return launch<TT, LTXK_EPI_BIAS_RES, false>(p, stream);
+    case LTXK_EPI_SCALE_RES: return launch<TT, LTXK_EPI_SCALE_RES, false>(p, stream);
   }
   ltxk_set_error("ltxk_gemm_bf16: unknown epilogue %d", epi);
   return LTXK_EINVAL;
@@ -265,7 +271,7 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   } else {
     LTXK_CHECK_ARG(a->ldo >= a->N && a->ldo % 4 == 0, "ltxk_gemm_bf16: ldo=%d (N=%d)", a->ldo, a->N);
   }
-  if (a->epilogue == LTXK_EPI_BIAS_GATE_RES || a->epilogue == LTXK_EPI_BIAS_RES) {
+  if (a->epilogue == LTXK_EPI_BIAS_GATE_RES || a->epilogue == LTXK_EPI_BIAS_RES || a->epilogue == LTXK_EPI_SCALE_RES) {
     LTXK_CHECK_ARG(a->resid != nullptr && a->ldr >= a->N && a->ldr % 4 == 0, "ltxk_gemm_bf16: residual epilogue needs resid/ldr");
   }
   if (a->epilogue == LTXK_EPI_BIAS_GATE_RES) {
@@ -276,7 +282,7 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.out = (bf16*)a->out; p.resid = (const bf16*)a->resid; p.gate = (const bf16*)a->gate;
   p.gate_row = a->gate_row;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldo = a->ldo; p.ldr = a->ldr;
-  p.gate_stride = a->gate_stride; p.T = trans ? a->out_tokens_per_batch : 1;
+  p.gate_stride = a->gate_stride; p.T = trans ? a->out_tokens_per_batch : 1; p.alpha = a->alpha;
   const int tt = pick_tt(a->M, a->N);
   const int bm = 32 * tt;
   p.RT = (a->M + bm - 1) / bm;

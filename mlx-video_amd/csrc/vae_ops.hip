@@ -231,6 +231,50 @@ __global__ __launch_bounds__(256) void s2d_skip_kernel(const bf16* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
+// GroupNorm3d (upsampler.py:65-98): fp32 mean/var over (voxels, C/G) per (batch, group), affine,
+// cast to bf16; then the ResBlock tail: [+ residual] [SiLU] (upsampler.py:160-174).
+// One workgroup per (batch, group); the volume is latent-sized (<= 9x24x24 voxels), so three
+// sweeps over it (mean, centred variance, apply) stay in L2.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void groupnorm_act_kernel(const bf16* __restrict__ x, bf16* __restrict__ out,
+                                                            const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                                            const bf16* __restrict__ resid, int64_t V, int C, int G,
+                                                            float eps, int apply_silu) {
+  __shared__ float red[8];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cg = C / G;
+  const bf16* xb = x + (int64_t)b * V * C + g * cg;
+  const int64_t n = V * cg;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (float)xb[(i / cg) * C + (i % cg)];
+  const float mean = block_sum(s) / (float)n;
+  float q = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float d = (float)xb[(i / cg) * C + (i % cg)] - mean;
+    q += d * d;
+  }
+  const float var = block_sum(q) / (float)n;
+  const float sd = sqrtf(var + eps);
+  bf16* ob = out + (int64_t)b * V * C + g * cg;
+  const bf16* rb = resid ? resid + (int64_t)b * V * C + g * cg : nullptr;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const int c = (int)(i % cg);
+    const int64_t off = (i / cg) * C + c;
+    float y = rbf(__fdiv_rn((float)xb[off] - mean, sd) * (float)gamma[g * cg + c] + (float)beta[g * cg + c]);
+    if (rb) y = rbf(y + (float)rb[off]);
+    if (apply_silu) y = y / (1.0f + expf(-y));
+    ob[off] = (bf16)y;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // tiled-decode blending (tiling.py:399-447,492-509): out += tile*mask, wsum += mask with
 // mask = mt[t]*mh[h]*mw[w] (fp32 accumulators); finalize: out/max(wsum,1e-8) -> bf16.
 // ---------------------------------------------------------------------------------------
@@ -267,6 +311,15 @@ __global__ void tile_blend_finalize_kernel(const float* __restrict__ acc, const 
 }  // namespace ltxk
 
 using namespace ltxk;
+
+extern "C" int ltxk_groupnorm_act(const void* x, void* out, const void* gamma, const void* beta, const void* resid,
+                                  int32_t B, int64_t V, int32_t C, int32_t G, float eps, int32_t apply_silu, void* stream) {
+  LTXK_CHECK_ARG(x && out && gamma && beta && B > 0 && V > 0 && C > 0 && G > 0 && C % G == 0, "ltxk_groupnorm_act: bad arguments");
+  hipLaunchKernelGGL(groupnorm_act_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,
+                     (const bf16*)gamma, (const bf16*)beta, (const bf16*)resid, V, C, G, eps, apply_silu);
+  LTXK_CHECK_LAUNCH("ltxk_groupnorm_act");
+  return LTXK_OK;
+}
 
 extern "C" int ltxk_tile_blend_accum(const void* tile, int32_t Tt, int32_t Th, int32_t Tw, int32_t at, int32_t ah,
                                      int32_t aw, const float* mt, const float* mh, const float* mw, float* acc,

@@ -1,0 +1,95 @@
+"""LoRA merge (mlx_video/lora.py:18-127): W += strength * (B @ A), product in fp32 on the matrix cores
+(ltxk_gemm_bf16 with the SCALE_RES epilogue), result rounded like the reference:
+bf16(W + bf16(strength * (B@A))).  One-time work at load (config 5 "merged LoRA")."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+@dataclass(frozen=True)
+class LoraSpec:
+    path: Path
+    strength: float = 1.0
+
+
+def _sanitize_lora_prefix(prefix: str) -> str:
+    """lora.py:18-33."""
+    for p in ("model.diffusion_model.", "diffusion_model."):
+        if prefix.startswith(p):
+            prefix = prefix[len(p):]
+    for a, b in ((".to_out.0.", ".to_out."), (".ff.net.0.proj.", ".ff.proj_in."), (".ff.net.2.", ".ff.proj_out."),
+                 (".audio_ff.net.0.proj.", ".audio_ff.proj_in."), (".audio_ff.net.2.", ".audio_ff.proj_out."),
+                 (".linear_1.", ".linear1."), (".linear_2.", ".linear2.")):
+        prefix = prefix.replace(a, b)
+    return prefix
+
+
+def _iter_lora_pairs(lora_sd: Dict[str, torch.Tensor]) -> Iterable[Tuple[str, str, torch.Tensor, torch.Tensor]]:
+    """lora.py:60-74: yield (base_key_raw, base_key_sanitized, A, B)."""
+    for key in lora_sd:
+        if not key.endswith(".lora_A.weight"):
+            continue
+        prefix = key[: -len(".lora_A.weight")]
+        kb = f"{prefix}.lora_B.weight"
+        if kb not in lora_sd:
+            continue
+        base = f"{prefix}.weight"
+        yield base, _sanitize_lora_prefix(base), lora_sd[key], lora_sd[kb]
+
+
+def _candidate_weight_keys(base_raw: str, base_sanitized: str) -> Tuple[str, ...]:
+    """lora.py:77-91."""
+    cand = [base_sanitized, base_raw]
+    if base_raw.startswith("diffusion_model."):
+        cand.append(f"model.{base_raw}")
+    if base_sanitized and not base_sanitized.startswith("model."):
+        cand += [f"diffusion_model.{base_sanitized}", f"model.diffusion_model.{base_sanitized}"]
+    return tuple(dict.fromkeys(cand))
+
+
+def load_lora_state(path: Path) -> Dict[str, torch.Tensor]:
+    from safetensors.torch import load_file
+    return load_file(str(path))
+
+
+def merge_lora_pair(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, strength: float) -> torch.Tensor:
+    """w (out,in), A (r,in), B (out,r) bf16 on the device -> bf16(w + bf16(strength * B@A)).
+    The rank axis is zero-padded to a multiple of 64 (the GEMM's K-step); zeros add nothing."""
+    r = A.shape[0]
+    rp = (r + 63) // 64 * 64
+    Bp = torch.zeros((B.shape[0], rp), dtype=BF16, device=w.device)
+    Bp[:, :r] = B.to(BF16)
+    At = torch.zeros((A.shape[1], rp), dtype=BF16, device=w.device)
+    At[:, :r] = A.to(BF16).t()
+    return ops.gemm(Bp, At, None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(), alpha=float(strength))
+
+
+def apply_lora_to_weights(weights: Dict[str, torch.Tensor], lora_specs: Iterable[LoraSpec], verbose: bool = False,
+                          lora_states: Dict[Path, Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """lora.py:94-127.  ``lora_states`` lets callers pass already-loaded LoRA tensors."""
+    updated = dict(weights)
+    for spec in lora_specs:
+        sd = (lora_states or {}).get(spec.path) or load_lora_state(spec.path)
+        applied = skipped = 0
+        for base_raw, base_san, A, B in _iter_lora_pairs(sd):
+            key = next((k for k in _candidate_weight_keys(base_raw, base_san) if k in updated), None)
+            if key is None:
+                skipped += 1
+                continue
+            w = updated[key]
+            dev = w.device
+            updated[key] = merge_lora_pair(w, A.to(dev), B.to(dev), spec.strength).reshape(w.shape)
+            applied += 1
+        if verbose:
+            print(f"[LoRA] {spec.path} applied={applied} skipped={skipped}")
+        elif applied == 0:
+            print(f"[LoRA] Warning: no weights applied for {spec.path}. Check key mapping.")
+    return updated

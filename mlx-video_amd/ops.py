@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import GemmArgs, check
 
-EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES, EPI_BIAS_RES = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES, EPI_BIAS_RES, EPI_SCALE_RES = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
 
 
@@ -73,7 +73,7 @@ def _req(t: torch.Tensor, dtype, name: str) -> None:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = EPI_BIAS,
          out: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          gate: Optional[torch.Tensor] = None, gate_row: Optional[torch.Tensor] = None,
-         gate_stride: int = 0, out_tokens_per_batch: int = 0) -> torch.Tensor:
+         gate_stride: int = 0, out_tokens_per_batch: int = 0, alpha: float = 1.0) -> torch.Tensor:
     """out = epi(a @ w.T + bias).  a (M,K) (row stride may exceed K), w (N,K) contiguous."""
     _req(a, BF16, "gemm.a"); _req(w, BF16, "gemm.w")
     M, K = a.shape
@@ -94,6 +94,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
     args.gate_stride = gate_stride
     args.epilogue = epilogue
     args.out_tokens_per_batch = out_tokens_per_batch
+    args.alpha = alpha
     with _timed("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
     return out

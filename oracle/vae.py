@@ -367,3 +367,77 @@ def decode_with_tiling(decode_fn: Callable[[Tensor], Tensor], latents: Tensor, s
                 out[:, :, t0:t1, h0:h1, w0:w1] += tile * m
                 wsum[:, :, t0:t1, h0:h1, w0:w1] += m
     return p.r(out / wsum.clamp_min(1e-8))
+
+
+# --------------------------------------------------------------------------------------
+# latent upsampler (models/ltx/upsampler.py:6-316)
+# --------------------------------------------------------------------------------------
+def conv3d_zero(x: Tensor, w: Tensor, b: Tensor, p: Prec) -> Tensor:
+    """upsampler.Conv3d: padding=1 zeros in all three dims (upsampler.py:6-62)."""
+    wt = w.to(p.dtype).permute(0, 4, 1, 2, 3).contiguous()
+    return p.r(F.conv3d(x.to(p.dtype), wt, b.to(p.dtype), padding=1))
+
+
+def group_norm3d(x: Tensor, gamma: Tensor, beta: Tensor, p: Prec, groups: int = 32, eps: float = 1e-5) -> Tensor:
+    """GroupNorm3d (upsampler.py:65-98): fp32 stats over (voxels, C/G); x channels-first here."""
+    b, c = x.shape[:2]
+    xf = x.float().reshape(b, groups, c // groups, -1)
+    mean = xf.mean(dim=(2, 3), keepdim=True)
+    var = ((xf - mean) ** 2).mean(dim=(2, 3), keepdim=True)
+    y = ((xf - mean) / torch.sqrt(var + eps)).reshape(x.shape)
+    return p.r(y * gamma.float().reshape(1, -1, 1, 1, 1) + beta.float().reshape(1, -1, 1, 1, 1))
+
+
+def upsampler_forward(latent: Tensor, W: Dict[str, Tensor], p: Prec, nb: int = 4) -> Tensor:
+    """LatentUpsampler.__call__ (upsampler.py:211-294), channels-first throughout."""
+    def res(x, pre):
+        h = conv3d_zero(x, W[f"{pre}.conv1.weight"], W[f"{pre}.conv1.bias"], p)
+        h = silu(group_norm3d(h, W[f"{pre}.norm1.weight"], W[f"{pre}.norm1.bias"], p), p)
+        h = conv3d_zero(h, W[f"{pre}.conv2.weight"], W[f"{pre}.conv2.bias"], p)
+        h = group_norm3d(h, W[f"{pre}.norm2.weight"], W[f"{pre}.norm2.bias"], p)
+        return silu(p.r(h + x), p)
+    x = conv3d_zero(p.r(latent), W["initial_conv.weight"], W["initial_conv.bias"], p)
+    x = silu(group_norm3d(x, W["initial_norm.weight"], W["initial_norm.bias"], p), p)
+    for i in range(nb):
+        x = res(x, f"res_blocks.{i}")
+    b, c, d, h, w = x.shape
+    x2 = x.permute(0, 2, 1, 3, 4).reshape(b * d, c, h, w)
+    w2 = W["upsampler.conv.weight"].to(p.dtype).permute(0, 3, 1, 2).contiguous()            # (O,3,3,I)->(O,I,3,3)
+    y = p.r(F.conv2d(x2.to(p.dtype), w2, W["upsampler.conv.bias"].to(p.dtype), padding=1))
+    y = F.pixel_shuffle(y, 2)                                                                 # channel (oc,ry,rx)
+    y = y.reshape(b, d, c, 2 * h, 2 * w).permute(0, 2, 1, 3, 4)
+    for i in range(nb):
+        y = res(y, f"post_upsample_res_blocks.{i}")
+    return conv3d_zero(y, W["final_conv.weight"], W["final_conv.bias"], p)
+
+
+def upsample_latents(latent: Tensor, W: Dict[str, Tensor], mean: Tensor, std: Tensor, p: Prec, nb: int = 4) -> Tensor:
+    """upsampler.py:297-316."""
+    m, s = mean.float().reshape(1, -1, 1, 1, 1), std.float().reshape(1, -1, 1, 1, 1)
+    x = p.r(p.r(latent) * s + m)
+    x = upsampler_forward(x, W, p, nb)
+    return p.r((x - m) / s)
+
+
+def make_upsampler_weights(mid: int = 128, seed: int = 99, dtype=torch.bfloat16, nb: int = 4) -> Dict[str, Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, Tensor] = {}
+
+    def conv(name, o, i):
+        W[f"{name}.weight"] = (torch.randn(o, 3, 3, 3, i, generator=g) / math.sqrt(27 * i)).to(dtype)
+        W[f"{name}.bias"] = (torch.randn(o, generator=g) * 0.01).to(dtype)
+
+    def norm(name, c):
+        W[f"{name}.weight"] = (1.0 + 0.1 * torch.randn(c, generator=g)).to(dtype)
+        W[f"{name}.bias"] = (0.1 * torch.randn(c, generator=g)).to(dtype)
+
+    conv("initial_conv", mid, 128)
+    norm("initial_norm", mid)
+    for stage in ("res_blocks", "post_upsample_res_blocks"):
+        for i in range(nb):
+            conv(f"{stage}.{i}.conv1", mid, mid); norm(f"{stage}.{i}.norm1", mid)
+            conv(f"{stage}.{i}.conv2", mid, mid); norm(f"{stage}.{i}.norm2", mid)
+    W["upsampler.conv.weight"] = (torch.randn(4 * mid, 3, 3, mid, generator=g) / math.sqrt(9 * mid)).to(dtype)
+    W["upsampler.conv.bias"] = (torch.randn(4 * mid, generator=g) * 0.01).to(dtype)
+    conv("final_conv", 128, mid)
+    return W

@@ -191,3 +191,41 @@ def test_encode_small(dev):
     assert rel_l2(out, ref) < 2e-2
     with pytest.raises(ValueError, match="1 \\+ 8"):
         enc(vid[:, :, :8].to(dev))
+
+
+def test_latent_upsampler(dev):
+    from mlx_video_amd.upsampler import LatentUpsampler, upsample_latents
+    W = OV.make_upsampler_weights(mid=128, nb=2)
+    up = LatentUpsampler({k: v.to(dev) for k, v in W.items()}, num_blocks_per_stage=2)
+    g = torch.Generator().manual_seed(8)
+    lat = torch.randn(1, 128, 3, 4, 5, generator=g).to(BF)
+    mean = (torch.randn(128, generator=g) * 0.1).to(BF)
+    std = (1 + 0.1 * torch.randn(128, generator=g)).abs().to(BF)
+    ref = OV.upsample_latents(lat.float(), W, mean, std, O.BF16, nb=2)
+    out = upsample_latents(lat.to(dev), up, mean.to(dev), std.to(dev))
+    torch.cuda.synchronize()
+    assert out.shape == (1, 128, 3, 8, 10) and ref.shape == out.shape
+    assert rel_l2(out, ref) < 2e-2
+
+
+def test_lora_merge(dev):
+    from mlx_video_amd.lora import LoraSpec, apply_lora_to_weights, merge_lora_pair
+    # reference known answer (tests/test_lora.py:8-29): I + 0.5*(1_{4x2}.1_{2x4}) = I + 1 -- at GEMM-legal sizes
+    n = 64
+    w = torch.eye(n).to(BF)
+    A, B = torch.ones(2, n).to(BF), torch.ones(n, 2).to(BF)
+    out = merge_lora_pair(w.to(dev), A.to(dev), B.to(dev), 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(out.float().cpu(), torch.eye(n) + 1.0)
+    g = torch.Generator().manual_seed(9)
+    w = (torch.randn(256, 128, generator=g) * 0.02).to(BF)
+    A = (torch.randn(16, 128, generator=g) * 0.1).to(BF)
+    B = (torch.randn(256, 16, generator=g) * 0.1).to(BF)
+    sd = {"diffusion_model.transformer_blocks.0.attn1.to_out.0.lora_A.weight": A,
+          "diffusion_model.transformer_blocks.0.attn1.to_out.0.lora_B.weight": B}
+    Wd = {"transformer_blocks.0.attn1.to_out.weight": w.to(dev)}
+    spec = LoraSpec(path="mem", strength=0.7)
+    merged = apply_lora_to_weights(Wd, [spec], lora_states={"mem": sd})["transformer_blocks.0.attn1.to_out.weight"]
+    torch.cuda.synchronize()
+    ref = O.BF16.r(w.float() + O.BF16.r(0.7 * (B.float() @ A.float())))
+    assert float((merged.float().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
