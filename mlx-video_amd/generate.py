@@ -1,0 +1,398 @@
+"""Pipeline driver with the surface of ``mlx_video.generate`` (generate.py:2035-4197, main() 4200-4758):
+``generate_video(...)`` for the distilled / dev / keyframe / ic_lora pipelines and a CLI.
+
+What is kept: argument names and meaning, dimension padding (/64 distilled-style, /32 dev) with crop
+back, frames -> 1+8k round-up, sigma schedules and subsampling, conditioning semantics (replace /
+guide, per-pipeline forcing), two-stage flow (half-res stage 1 -> latent upsample -> re-noise ->
+stage 2, optional stage-2 LoRA transformer), tiling policy, the `_PhaseTimer` phase names
+(`stage1_denoise`, `upsample`, `stage2_denoise`, `dev_denoise`, `vae_decode`, `to_uint8_numpy`) and
+the `--profile-json` payload.
+
+What is injected instead of loaded (nothing exists offline and they are out of scope, SURVEY.md §2a
+#17/#21): text embeddings (the Gemma-3 text encoder's output tensor is an INPUT of this path), model
+weights (`weights=` dicts or ready modules; `model_repo` may point at a local directory of
+safetensors read by ``weights.py``), random draws (`noise_fn`: MLX's threefry stream is not
+reproducible, so seeds are not cross-compatible), audio (not supported).  mp4/ffmpeg writing is out
+of scope: frames are returned as the reference returns them (uint8 (F,H,W,3)) and `output_path`
+accepts `.npy`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import time
+from contextlib import contextmanager
+from enum import Enum
+from pathlib import Path
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .conditioning import (LatentState, VideoConditionByKeyframeIndex, VideoConditionByLatentIndex, apply_conditioning,
+                           noise_blend)
+from .denoise import denoise_dev, denoise_distilled
+from .ltx_model import LTXModel, LTXModelConfig
+from .schedulers import (STAGE_1_SIGMAS, STAGE_2_SIGMAS, _subsample_refinement_sigmas, _subsample_sigmas,
+                         create_position_grid, ltx2_scheduler)
+from .video_vae import LTX2VideoDecoder, TilingConfig, VideoEncoder, to_uint8_frames
+
+BF16 = torch.bfloat16
+DEFAULT_NEGATIVE_PROMPT = ""
+
+
+class PipelineType(Enum):
+    """generate.py:299-304."""
+    DISTILLED = "distilled"
+    DEV = "dev"
+    KEYFRAME = "keyframe"
+    IC_LORA = "ic_lora"
+
+
+class _PhaseTimer:
+    """generate.py:64-94 (phases are closed with a device sync so they mean GPU time)."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self.times_s: Dict[str, float] = {}
+
+    @contextmanager
+    def phase(self, name: str):
+        if not self.enabled:
+            yield
+            return
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            yield
+        finally:
+            torch.cuda.synchronize()
+            self.times_s[name] = self.times_s.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def render(self, elapsed_s: float) -> str:
+        if not self.times_s:
+            return ""
+        total = sum(self.times_s.values())
+        denom = total if total > 0 else (elapsed_s if elapsed_s > 0 else 1.0)
+        lines = [f"{n:>18}: {dt:6.2f}s ({100.0 * dt / denom:5.1f}%)"
+                 for n, dt in sorted(self.times_s.items(), key=lambda kv: kv[1], reverse=True)]
+        lines += [f"{'total(phases)':>18}: {total:6.2f}s", f"{'elapsed(wall)':>18}: {elapsed_s:6.2f}s"]
+        return "\n".join(lines)
+
+
+def _default_noise_fn(seed: int, device) -> Callable[[Tuple[int, ...]], torch.Tensor]:
+    g = torch.Generator(device=device).manual_seed(int(seed))
+    return lambda shape: torch.randn(shape, generator=g, device=device, dtype=torch.float32).to(BF16)
+
+
+def _pad_dims(height: int, width: int, divisor: int):
+    """generate.py:2238-2259: pad to a multiple of `divisor`, remember the crop."""
+    if height % divisor == 0 and width % divisor == 0:
+        return height, width, None
+    ph, pw = (-height) % divisor, (-width) % divisor
+    top, left = ph // 2, pw // 2
+    return height + ph, width + pw, (top, left, height, width)
+
+
+def _round_frames(num_frames: int) -> int:
+    """generate.py:2261-2266: round UP to 1 + 8k."""
+    return num_frames if num_frames % 8 == 1 else ((num_frames - 1 + 7) // 8) * 8 + 1
+
+
+def _resolve_frame_idx(frame_idx: int, num_frames: int, latent_frames: int) -> int:
+    """generate.py:2612-2619."""
+    if frame_idx < latent_frames:
+        return frame_idx
+    if num_frames <= 1 or latent_frames <= 1:
+        return 0
+    return int(max(0, min(latent_frames - 1, int((frame_idx / (num_frames - 1) * (latent_frames - 1)) + 0.5))))
+
+
+def _encode_conditionings(items, encoder: Optional[VideoEncoder], height: int, width: int, num_frames: int,
+                          latent_frames: int, guide: bool, device):
+    """items: (pixels (1,3,F,H,W) in [-1,1] | latent (1,128,f,h,w), frame_idx, strength).  Pixel
+    tensors are encoded with the VAE encoder at the stage's resolution (generate.py:3064-3113)."""
+    out = []
+    for src, frame_idx, strength in items:
+        if not torch.is_tensor(src):
+            raise ValueError("image/video conditioning must be given as tensors (file decoding via cv2/PIL is "
+                             "conditioning-input I/O, SURVEY.md §8f row 4)")
+        t = src.to(device)
+        if t.shape[1] == 3:
+            if encoder is None:
+                raise ValueError("pixel conditioning needs a VAE encoder (pass vae_encoder=)")
+            if tuple(t.shape[-2:]) != (height, width):
+                raise ValueError(f"conditioning frames must already be {width}x{height}, got {t.shape[-1]}x{t.shape[-2]}")
+            t = encoder(t.to(BF16))
+        idx = _resolve_frame_idx(int(frame_idx), num_frames, latent_frames)
+        out.append(VideoConditionByKeyframeIndex(t, idx, float(strength)) if guide
+                   else VideoConditionByLatentIndex(t, idx, float(strength)))
+    return out
+
+
+def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional[str] = None, prompt: str = "",
+                   pipeline: PipelineType = PipelineType.DISTILLED, negative_prompt: str = DEFAULT_NEGATIVE_PROMPT,
+                   height: int = 512, width: int = 512, num_frames: int = 33, num_inference_steps: int = 40,
+                   cfg_scale: float = 4.0, seed: int = 42, fps: float = 24.0, output_path: Optional[str] = None,
+                   save_frames: bool = False, verbose: bool = False, profile: bool = False,
+                   profile_json_path: Optional[str] = None, image=None, image_strength: float = 1.0,
+                   image_frame_idx: int = 0, images: Optional[list] = None, video_conditionings: Optional[list] = None,
+                   distilled_loras: Optional[list] = None, conditioning_mode: str = "replace", tiling: str = "auto",
+                   stream: bool = False, audio: bool = False, eval_interval: int = 1, compile_step: bool = False,
+                   compile_shapeless: bool = False, cfg_batch: bool = False, fp32_euler: bool = True,
+                   loras: Optional[list] = None, stage2_dev: bool = False, stage1_steps: int = 8, stage2_steps: int = 3,
+                   sigma_subsample: str = "farthest",
+                   # ---- injected in place of what the reference downloads / samples ----
+                   transformer: Optional[LTXModel] = None, stage2_transformer: Optional[LTXModel] = None,
+                   vae_decoder: Optional[LTX2VideoDecoder] = None, vae_encoder: Optional[VideoEncoder] = None,
+                   upsampler=None, prompt_embeds: Optional[torch.Tensor] = None,
+                   negative_prompt_embeds: Optional[torch.Tensor] = None, text_encoder: Optional[Callable] = None,
+                   noise_fn: Optional[Callable] = None, device=None, on_frames_ready: Optional[Callable] = None,
+                   return_latents: bool = False) -> np.ndarray:
+    """See the module docstring.  Returns uint8 frames (F,H,W,3) (generate.py:4195-4197)."""
+    t_start = time.perf_counter()
+    if isinstance(pipeline, str):
+        pipeline = PipelineType(pipeline)
+    if audio:
+        raise ValueError("audio generation is not supported (audio branch is out of scope, SURVEY.md §2a #21)")
+    images_list = list(images or [])
+    if image is not None:
+        images_list.append((image, image_frame_idx, image_strength))
+    video_conditionings = list(video_conditionings or [])
+    if conditioning_mode not in ("replace", "guide"):
+        raise ValueError(f"Unknown conditioning_mode: {conditioning_mode}")
+    if pipeline == PipelineType.KEYFRAME:                         # generate.py:2223-2225
+        conditioning_mode = "guide"
+    if pipeline == PipelineType.IC_LORA:                          # generate.py:2226-2229
+        if not video_conditionings:
+            raise ValueError("IC-LoRA pipeline requires --video-conditioning PATH [FRAME_IDX] STRENGTH")
+        conditioning_mode = "replace"
+    is_distilled = pipeline in (PipelineType.DISTILLED, PipelineType.KEYFRAME, PipelineType.IC_LORA)
+    if pipeline == PipelineType.DEV and video_conditionings:     # generate.py:2234-2235
+        raise ValueError("Video conditioning is only supported in ic_lora/distilled pipelines.")
+    if sigma_subsample not in ("uniform", "farthest"):
+        raise ValueError(f"Unknown sigma subsample method: {sigma_subsample}")
+
+    out_h, out_w = height, width
+    height, width, crop = _pad_dims(height, width, 64 if is_distilled else 32)
+    num_frames = _round_frames(num_frames)
+    latent_frames = 1 + (num_frames - 1) // 8
+
+    if transformer is None:
+        if model_repo is None:
+            raise FileNotFoundError("no transformer: pass transformer= or a local model_repo directory with LTX-2 safetensors")
+        from .weights import load_pipeline_modules
+        mods = load_pipeline_modules(model_repo, device, need_encoder=bool(images_list or video_conditionings),
+                                     need_upsampler=is_distilled, loras=loras)
+        transformer, vae_decoder = mods["transformer"], vae_decoder or mods["vae_decoder"]
+        vae_encoder, upsampler = vae_encoder or mods.get("vae_encoder"), upsampler or mods.get("upsampler")
+    if vae_decoder is None:
+        raise FileNotFoundError("no VAE decoder: pass vae_decoder= or a model_repo containing VAE weights")
+    dev = device or transformer.tables.device
+    if noise_fn is None:
+        noise_fn = _default_noise_fn(seed, dev)
+
+    if prompt_embeds is None:
+        if text_encoder is None:
+            raise ValueError("prompt_embeds is required: the Gemma-3 text encoder is outside this package "
+                             "(SURVEY.md §2a #17); pass prompt_embeds=(1,1024,3840) or text_encoder=callable")
+        prompt_embeds = text_encoder(prompt)
+        negative_prompt_embeds = text_encoder(negative_prompt)
+    ctx_pos = prompt_embeds.to(dev).to(BF16)
+    ctx_neg = (negative_prompt_embeds if negative_prompt_embeds is not None else torch.zeros_like(prompt_embeds)).to(dev).to(BF16)
+
+    timer = _PhaseTimer(profile or bool(profile_json_path))
+    guide = conditioning_mode == "guide"
+
+    def init_state(shape, conds, sigma0):
+        """generate.py:3139-3160 / 3430-3449: zeros -> apply_conditioning -> masked noise blend."""
+        st = LatentState(torch.zeros(shape, dtype=BF16, device=dev), torch.zeros(shape, dtype=BF16, device=dev),
+                         torch.ones((1, 1, shape[2], 1, 1), dtype=BF16, device=dev))
+        st = apply_conditioning(st, conds)
+        return noise_blend(st, noise_fn(shape), float(sigma0))
+
+    if is_distilled:
+        if upsampler is None:
+            raise FileNotFoundError("the two-stage pipelines need the latent upsampler (pass upsampler=)")
+        s1h, s1w, s2h, s2w = height // 2 // 32, width // 2 // 32, height // 32, width // 32
+        sig1 = _subsample_sigmas(list(STAGE_1_SIGMAS), stage1_steps, sigma_subsample)
+        sig2 = _subsample_refinement_sigmas(list(STAGE_2_SIGMAS), stage2_steps, sigma_subsample)
+        cond_items = images_list + video_conditionings
+        conds1, conds2 = [], []
+        if cond_items:
+            with timer.phase("cond_encode"):
+                # the reference loads each file twice, resized to the half- and full-resolution stage
+                # (generate.py:3064-3113); with tensors the half-resolution copy is an antialiased resample
+                # (conditioning-input preprocessing, not part of the denoise/VAE hot path)
+                import torch.nn.functional as F
+                half = []
+                for src, fi, st_ in cond_items:
+                    if src.shape[1] != 3:
+                        raise ValueError("two-stage pipelines take pixel conditionings (encoded at both resolutions)")
+                    b_, c_, f_, h_, w_ = src.shape
+                    hs = F.interpolate(src.float().permute(0, 2, 1, 3, 4).reshape(b_ * f_, c_, h_, w_), size=(height // 2, width // 2),
+                                       mode="bilinear", antialias=True, align_corners=False)
+                    half.append((hs.reshape(b_, f_, c_, height // 2, width // 2).permute(0, 2, 1, 3, 4).contiguous(), fi, st_))
+                conds1 = _encode_conditionings(half, vae_encoder, height // 2, width // 2, num_frames, latent_frames, guide, dev)
+                conds2 = _encode_conditionings(cond_items, vae_encoder, height, width, num_frames, latent_frames, guide, dev)
+        shape1 = (1, 128, latent_frames, s1h, s1w)
+        pos1 = create_position_grid(1, latent_frames, s1h, s1w, fps=fps).to(dev)
+        state1 = init_state(shape1, conds1, sig1[0]) if conds1 else None
+        latents = state1.latent if state1 is not None else noise_fn(shape1)
+        with timer.phase("stage1_denoise"):
+            latents, _ = denoise_distilled(latents, pos1, ctx_pos, transformer, sig1, state=state1,
+                                           compile_step=compile_step, fp32_euler=fp32_euler)
+        with timer.phase("upsample"):
+            from .upsampler import upsample_latents
+            latents = upsample_latents(latents, upsampler, vae_decoder.latents_mean, vae_decoder.latents_std)
+        tr2 = stage2_transformer or transformer
+        pos2 = create_position_grid(1, latent_frames, s2h, s2w, fps=fps).to(dev)
+        state2 = None
+        if conds2:                                                  # generate.py:3290-3311
+            st = LatentState(latents, torch.zeros_like(latents), torch.ones((1, 1, latent_frames, 1, 1), dtype=BF16, device=dev))
+            state2 = noise_blend(apply_conditioning(st, conds2), noise_fn(tuple(latents.shape)), float(sig2[0]))
+            latents = state2.latent
+        else:                                                       # generate.py:3317-3321
+            s0 = torch.tensor(sig2[0], dtype=BF16, device=dev)
+            latents = (noise_fn(tuple(latents.shape)) * s0 + latents * torch.tensor(1.0 - sig2[0], dtype=BF16, device=dev)).to(BF16)
+        with timer.phase("stage2_denoise"):
+            if stage2_dev:
+                latents = denoise_dev(latents, pos2, ctx_pos, ctx_neg, tr2, torch.tensor(sig2), cfg_scale=cfg_scale,
+                                      state=state2, compile_step=compile_step, cfg_batch=cfg_batch)
+            else:
+                latents, _ = denoise_distilled(latents, pos2, ctx_pos, tr2, sig2, state=state2, compile_step=compile_step,
+                                               fp32_euler=fp32_euler)
+    else:
+        lh, lw = height // 32, width // 32
+        n_tok = latent_frames * lh * lw
+        sigmas = ltx2_scheduler(num_inference_steps, n_tok)          # generate.py:3410-3411
+        pos = create_position_grid(1, latent_frames, lh, lw, fps=fps).to(dev)
+        shape = (1, 128, latent_frames, lh, lw)
+        conds = []
+        if images_list:
+            with timer.phase("cond_encode"):
+                conds = _encode_conditionings(images_list, vae_encoder, height, width, num_frames, latent_frames, guide, dev)
+        state = init_state(shape, conds, float(sigmas[0])) if conds else None
+        latents = state.latent if state is not None else noise_fn(shape)
+        with timer.phase("dev_denoise"):
+            latents = denoise_dev(latents, pos, ctx_pos, ctx_neg, transformer, sigmas, cfg_scale=cfg_scale, state=state,
+                                  compile_step=compile_step, cfg_batch=cfg_batch)
+
+    if return_latents:
+        return latents
+    # ---- VAE decode (generate.py:3794-3830) ----
+    tcfg = None
+    if tiling == "auto":
+        tcfg = TilingConfig.auto(height, width, num_frames)
+    elif tiling not in ("none", None):
+        tcfg = {"default": TilingConfig.default, "aggressive": TilingConfig.aggressive,
+                "conservative": TilingConfig.conservative, "spatial": TilingConfig.spatial_only,
+                "temporal": TilingConfig.temporal_only}[tiling]()
+    dec_noise = noise_fn(tuple(latents.shape)) if vae_decoder.timestep_conditioning else None
+    with timer.phase("vae_decode"):
+        if tcfg is not None and (tiling != "auto" or stream):
+            video = vae_decoder.decode_tiled(latents, tiling_config=tcfg, tiling_mode=tiling, on_frames_ready=on_frames_ready)
+        else:
+            # "auto": the reference first tries the non-tiled decode and only falls back on an OOM-looking
+            # exception (generate.py:3798-3818); 288 GB of HBM never takes that fallback at these sizes.
+            video = vae_decoder(latents, noise=dec_noise) if dec_noise is not None else vae_decoder(latents)
+    with timer.phase("to_uint8_numpy"):
+        frames = to_uint8_frames(video)[0]
+        video_np = frames.cpu().numpy()
+        if crop is not None:
+            top, left, oh, ow = crop
+            video_np = video_np[:, top:top + oh, left:left + ow, :]
+    elapsed = time.perf_counter() - t_start
+    if output_path:
+        p = Path(output_path)
+        if p.suffix != ".npy":
+            raise ValueError("only .npy output is supported (mp4/ffmpeg writing is out of scope, SURVEY.md §2a #1)")
+        p.parent.mkdir(parents=True, exist_ok=True)
+        np.save(p, video_np)
+    if profile and verbose:
+        print(timer.render(elapsed))
+    if profile_json_path and timer.times_s:                          # generate.py:4158-4189 (same keys)
+        outp = Path(output_path).with_suffix(".profile.json") if profile_json_path == "auto" and output_path else Path(profile_json_path)
+        payload = {"elapsed_s": float(elapsed), "num_frames": int(num_frames), "fps": float(fps), "pipeline": pipeline.value,
+                   "stage1_steps": int(stage1_steps) if is_distilled else None,
+                   "stage2_steps": int(stage2_steps) if is_distilled else None, "eval_interval": int(eval_interval),
+                   "compile_step": bool(compile_step), "compile_shapeless": bool(compile_shapeless),
+                   "fp32_euler": bool(fp32_euler), "audio": False, "phases_s": {k: float(v) for k, v in timer.times_s.items()},
+                   "peak_memory_gb": float(torch.cuda.max_memory_allocated() / (1024 ** 3))}
+        outp.parent.mkdir(parents=True, exist_ok=True)
+        outp.write_text(json.dumps(payload, indent=2, sort_keys=True), encoding="utf-8")
+    return video_np
+
+
+def build_parser() -> argparse.ArgumentParser:
+    """The subset of generate.py:4244-4525 that drives this path."""
+    ap = argparse.ArgumentParser(description="LTX-2 video generation on MI355X (libltxk)")
+    ap.add_argument("--prompt", type=str, default="")
+    ap.add_argument("--negative-prompt", type=str, default=DEFAULT_NEGATIVE_PROMPT)
+    ap.add_argument("--pipeline", choices=[p.value for p in PipelineType], default="distilled")
+    ap.add_argument("--model-repo", type=str, default=None)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--num-frames", type=int, default=33)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--cfg-scale", type=float, default=4.0)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--fps", type=float, default=24.0)
+    ap.add_argument("--output-path", type=str, default="output.npy")
+    ap.add_argument("--tiling", type=str, default="auto")
+    ap.add_argument("--stage1-steps", type=int, default=None)
+    ap.add_argument("--stage2-steps", type=int, default=None)
+    ap.add_argument("--sigma-subsample", choices=["uniform", "farthest"], default="farthest")
+    ap.add_argument("--compile", dest="compile_step", action="store_true", default=None)
+    ap.add_argument("--cfg-batch", action="store_true", default=None)
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--profile-json", type=str, default=None)
+    ap.add_argument("--prompt-embeds", type=str, default=None, help=".pt/.npy file with (1,1024,3840) text embeddings")
+    ap.add_argument("--negative-prompt-embeds", type=str, default=None)
+    ap.add_argument("--synthetic", action="store_true", help="random-init weights + random text embeddings (no checkpoints offline)")
+    ap.add_argument("--layers", type=int, default=48)
+    return ap
+
+
+def main(argv: Optional[Sequence[str]] = None) -> None:
+    args = build_parser().parse_args(argv)
+    is_dev = args.pipeline == "dev"
+    # CLI heuristics of generate.py:4545-4552,4629-4644
+    if args.stage1_steps is None:
+        args.stage1_steps = 5 if args.pipeline == "distilled" else 8
+    if args.stage2_steps is None:
+        args.stage2_steps = 1 if args.pipeline == "distilled" else 3
+    if args.compile_step is None:
+        args.compile_step = is_dev and args.steps >= 8
+    if args.cfg_batch is None:
+        args.cfg_batch = is_dev and args.cfg_scale > 1.0
+    dev = torch.device("cuda:0")
+    kw = {}
+    if args.synthetic:
+        from .video_vae import random_decoder_weights
+        kw["transformer"] = LTXModel.random_init(LTXModelConfig(num_layers=args.layers), dev)
+        kw["vae_decoder"] = LTX2VideoDecoder(random_decoder_weights(dev))
+        g = torch.Generator(device=dev).manual_seed(43)
+        kw["prompt_embeds"] = torch.randn((1, 1024, 3840), generator=g, device=dev).to(BF16)
+        kw["negative_prompt_embeds"] = torch.randn((1, 1024, 3840), generator=g, device=dev).to(BF16)
+        if not is_dev:
+            from .upsampler import LatentUpsampler
+            from .weights import random_upsampler_weights
+            kw["upsampler"] = LatentUpsampler(random_upsampler_weights(dev))
+    else:
+        def _load(path):
+            return torch.from_numpy(np.load(path)) if path.endswith(".npy") else torch.load(path, weights_only=True)
+        if args.prompt_embeds:
+            kw["prompt_embeds"] = _load(args.prompt_embeds)
+        if args.negative_prompt_embeds:
+            kw["negative_prompt_embeds"] = _load(args.negative_prompt_embeds)
+    generate_video(model_repo=args.model_repo, prompt=args.prompt, pipeline=PipelineType(args.pipeline),
+                   negative_prompt=args.negative_prompt, height=args.height, width=args.width, num_frames=args.num_frames,
+                   num_inference_steps=args.steps, cfg_scale=args.cfg_scale, seed=args.seed, fps=args.fps,
+                   output_path=args.output_path, tiling=args.tiling, compile_step=args.compile_step, cfg_batch=args.cfg_batch,
+                   profile=args.profile, profile_json_path=args.profile_json, stage1_steps=args.stage1_steps,
+                   stage2_steps=args.stage2_steps, sigma_subsample=args.sigma_subsample, verbose=True, device=dev, **kw)
+
+
+if __name__ == "__main__":
+    main()

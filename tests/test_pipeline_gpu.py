@@ -1,0 +1,131 @@
+"""End-to-end pipelines on the GPU: the dev pipeline (config 1: 128x128x9, T2V and I2V) against the
+oracle composed end to end (denoise loop -> VAE decode -> uint8), and the three two-stage pipelines
+(distilled / keyframe / ic_lora) for plumbing: shapes, dtype, finiteness, phase names, error behaviour.
+Tolerance for uint8 frames after a full generate: mean |diff| <= 1.5 grey levels, 99 % within 6."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit as O
+from oracle import vae as OV
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def _mods(dev, enc_blocks=None):
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+    from mlx_video_amd.upsampler import LatentUpsampler
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, VideoEncoder
+    cfg = O.DiTConfig(num_layers=2, heads=4, caption_channels=256)
+    W = O.make_weights(cfg, seed=31)
+    mc = LTXModelConfig(num_attention_heads=4, num_layers=2, caption_channels=256, cross_attention_dim=cfg.dim)
+    Wd = OV.make_decoder_weights(seed=32, layers_per_block=1)
+    blocks = [("res_x", 1), ("compress_space_res", (1, 2, 2)), ("res_x", 1), ("compress_time_res", (2, 1, 1)),
+              ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1)]
+    We = OV.make_encoder_weights(seed=33, blocks=blocks)
+    Wu = OV.make_upsampler_weights(mid=128, nb=1)
+    return dict(cfg=cfg, W=W, Wd=Wd, We=We, blocks=blocks, Wu=Wu,
+                transformer=LTXModel(mc, {k: v.to(dev) for k, v in W.items()}),
+                vae_decoder=LTX2VideoDecoder({k: v.to(dev) for k, v in Wd.items()}, num_layers_per_block=1),
+                vae_encoder=VideoEncoder({k: v.to(dev) for k, v in We.items()}, encoder_blocks=blocks),
+                upsampler=LatentUpsampler({k: v.to(dev) for k, v in Wu.items()}, num_blocks_per_stage=1))
+
+
+class _Noise:
+    """Deterministic noise source shared by the product run and the oracle run."""
+
+    def __init__(self, seed, dev=None):
+        self.g = torch.Generator().manual_seed(seed)
+        self.dev = dev
+        self.log = []
+
+    def __call__(self, shape):
+        n = torch.randn(shape, generator=self.g).to(BF)
+        self.log.append(n)
+        return n.to(self.dev) if self.dev is not None else n
+
+
+@pytest.mark.parametrize("i2v", [False, True])
+def test_dev_pipeline_matches_oracle(dev, tmp_path, i2v):
+    from mlx_video_amd.generate import PipelineType, generate_video
+    from mlx_video_amd.schedulers import ltx2_scheduler
+    m = _mods(dev)
+    g = torch.Generator().manual_seed(50)
+    pe_pos = torch.randn(1, 64, 256, generator=g).to(BF)
+    pe_neg = torch.randn(1, 64, 256, generator=g).to(BF)
+    img = (torch.rand(1, 3, 1, 128, 128, generator=g) * 2 - 1).to(BF)
+    noise = _Noise(7, dev)
+    pj = tmp_path / "p.json"
+    frames = generate_video(prompt="x", pipeline=PipelineType.DEV, height=128, width=128, num_frames=9,
+                            num_inference_steps=2, cfg_scale=4.0, transformer=m["transformer"], vae_decoder=m["vae_decoder"],
+                            vae_encoder=m["vae_encoder"], prompt_embeds=pe_pos, negative_prompt_embeds=pe_neg, noise_fn=noise,
+                            images=[(img, 0, 1.0)] if i2v else None, compile_step=True, cfg_batch=True, device=dev,
+                            profile_json_path=str(pj), output_path=str(tmp_path / "o.npy"))
+    assert frames.shape == (9, 128, 128, 3) and frames.dtype == np.uint8
+    assert np.array_equal(np.load(tmp_path / "o.npy"), frames)
+    prof = json.loads(pj.read_text())
+    assert prof["pipeline"] == "dev" and {"dev_denoise", "vae_decode", "to_uint8_numpy"} <= set(prof["phases_s"])
+    # ---- oracle, same noise ----
+    p = O.BF16
+    sig = ltx2_scheduler(2, 2 * 4 * 4)
+    pos = O.create_position_grid(1, 2, 4, 4)
+    n0 = noise.log[0].float()
+    clean = mask = None
+    lat0 = n0
+    if i2v:
+        z = OV.vae_encode(img.float(), m["We"], p, m["blocks"])
+        from oracle import sched as S
+        l0, clean, mask = S.apply_conditioning(torch.zeros(1, 128, 2, 4, 4), torch.zeros(1, 128, 2, 4, 4), torch.ones(1, 1, 2, 1, 1),
+                                               [("replace", z, 0, 1.0)])
+        sm = p.r(mask * O.bf16_round_scalar(float(sig[0])))
+        lat0 = p.r(p.r(n0 * sm) + p.r(l0 * p.r(1.0 - sm)))
+    lat = O.denoise_dev(lat0, pos, pe_pos.float(), pe_neg.float(), m["W"], m["cfg"], sig.tolist(), p, 4.0, clean, mask, compiled=True)
+    vid = OV.vae_decode(lat, m["Wd"], p, layers_per_block=1)
+    ref = OV.to_uint8(vid[0], p).numpy()
+    d = np.abs(frames.astype(np.int32) - ref.astype(np.int32))
+    assert d.mean() <= 1.5 and np.percentile(d, 99) <= 6, (d.mean(), np.percentile(d, 99))
+
+
+@pytest.mark.parametrize("pipe", ["distilled", "keyframe", "ic_lora"])
+def test_two_stage_pipelines_run(dev, pipe):
+    from mlx_video_amd.generate import PipelineType, generate_video
+    m = _mods(dev)
+    g = torch.Generator().manual_seed(51)
+    emb = torch.randn(1, 64, 256, generator=g).to(BF)
+    kw = {}
+    if pipe == "keyframe":
+        kw["images"] = [((torch.rand(1, 3, 1, 128, 128, generator=g) * 2 - 1).to(BF), 0, 1.0),
+                        ((torch.rand(1, 3, 1, 128, 128, generator=g) * 2 - 1).to(BF), 8, 0.8)]
+    if pipe == "ic_lora":
+        kw["video_conditionings"] = [((torch.rand(1, 3, 9, 128, 128, generator=g) * 2 - 1).to(BF), 0, 1.0)]
+    frames = generate_video(prompt="x", pipeline=PipelineType(pipe), height=128, width=128, num_frames=9, stage1_steps=2,
+                            stage2_steps=1, transformer=m["transformer"], vae_decoder=m["vae_decoder"], vae_encoder=m["vae_encoder"],
+                            upsampler=m["upsampler"], prompt_embeds=emb, device=dev, seed=3, **kw)
+    assert frames.shape == (9, 128, 128, 3) and frames.dtype == np.uint8
+    assert 5 < frames.mean() < 250
+
+
+def test_pipeline_surface_and_errors(dev):
+    from mlx_video_amd.generate import PipelineType, _pad_dims, _resolve_frame_idx, _round_frames, generate_video
+    from mlx_video_amd.pipelines import TI2VidOneStagePipeline
+    assert _round_frames(33) == 33 and _round_frames(30) == 33 and _round_frames(34) == 41      # round UP (generate.py:2261-2266)
+    assert _pad_dims(480, 832, 64) == (512, 832, (16, 0, 480, 832)) and _pad_dims(512, 512, 32) == (512, 512, None)
+    assert _resolve_frame_idx(3, 33, 5) == 3 and _resolve_frame_idx(32, 33, 5) == 4 and _resolve_frame_idx(16, 33, 5) == 2
+    m = _mods(dev)
+    emb = torch.zeros(1, 64, 256, dtype=BF)
+    with pytest.raises(ValueError, match="IC-LoRA pipeline requires"):
+        generate_video(pipeline=PipelineType.IC_LORA, transformer=m["transformer"], vae_decoder=m["vae_decoder"], prompt_embeds=emb)
+    with pytest.raises(ValueError, match="only supported in ic_lora/distilled"):
+        generate_video(pipeline=PipelineType.DEV, transformer=m["transformer"], vae_decoder=m["vae_decoder"], prompt_embeds=emb,
+                       video_conditionings=[(torch.zeros(1, 3, 9, 64, 64), 0, 1.0)])
+    with pytest.raises(ValueError, match="prompt_embeds is required"):
+        generate_video(pipeline=PipelineType.DEV, transformer=m["transformer"], vae_decoder=m["vae_decoder"])
+    with pytest.raises(ValueError, match="audio"):
+        generate_video(pipeline=PipelineType.DEV, audio=True, transformer=m["transformer"], vae_decoder=m["vae_decoder"], prompt_embeds=emb)
+    # padded dims: 100x120 -> 128x128 internally, cropped back
+    pipe = TI2VidOneStagePipeline(height=100, width=120, num_frames=9, steps=1)
+    fr = pipe("x", output_path=None, transformer=m["transformer"], vae_decoder=m["vae_decoder"], prompt_embeds=emb, device=dev)
+    assert fr.shape == (9, 100, 120, 3)
