@@ -91,3 +91,63 @@ def test_model_strict_load_and_sanitize():
     assert set(s) == {"transformer_blocks.0.attn1.to_out.weight", "transformer_blocks.0.ff.proj_in.bias",
                       "transformer_blocks.0.ff.proj_out.weight", "adaln_single.emb.timestep_embedder.linear1.weight"}
     assert len(LTXModel.expected_keys(LTXModelConfig())) == 15 + 48 * 25
+
+
+def test_component_hook_contracts():
+    from mlx_video_amd import components as C
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 3, 4, 5, generator=g)
+    x0 = torch.randn(2, 8, 3, 4, 5, generator=g)
+    sig = torch.tensor([0.9, 0.6, 0.0])
+    # Euler via velocity == the denoise loop's form x0 + s'(x-x0)/s
+    out = C.EulerDiffusionStep().execute(x, x0, sig, 0)
+    assert torch.allclose(out, O.euler_step(x, x0, 0.9, 0.6, O.F32), atol=1e-5)
+    assert torch.allclose(C.EulerDiffusionStep().execute(x, x0, sig, 1), x0, atol=1e-5)     # last step lands on x0
+    c, u = torch.tensor([[[1.0, 2.0, 3.0]]]), torch.tensor([[[0.5, 1.0, 1.5]]])
+    assert torch.equal(C.CFGGuider(4.0).delta(c, u), torch.tensor([[[1.5, 3.0, 4.5]]])) and not C.CFGGuider(1.0).enabled()
+    assert C.STGGuider(0.0).enabled() is False and C.LtxAPGGuider(3.0).enabled()
+    # CFG* with uncond parallel to cond: rescaled negative equals cond -> zero delta
+    assert float(C.CFGStarRescalingGuider(4.0).delta(c, 0.5 * c).abs().max()) < 1e-6
+    pz = C.VideoLatentPatchifier(1)
+    tok = pz.patchify(x)
+    assert tok.shape == (2, 60, 8) and pz.get_token_count(x.shape) == 60
+    assert torch.equal(tok, O.latent_to_tokens(x)) and torch.equal(pz.unpatchify(tok, x.shape), x)
+    n = C.GaussianNoiser(seed=3)
+    assert torch.equal(n.noise(x), n.noise(x)) and n.noise(x.bfloat16()).dtype == torch.bfloat16
+    lq = C.LinearQuadraticScheduler().execute(8)
+    assert lq.shape == (9,) and lq[0] == 1.0 and abs(float(lq[-1])) < 1e-6 and all(lq[i] > lq[i + 1] for i in range(8))
+    bs = C.BetaScheduler().execute(8)
+    assert bs[-1] == 0.0 and all(bs[i] >= bs[i + 1] for i in range(len(bs) - 1))
+    from mlx_video_amd.schedulers import LTX2Scheduler, ltx2_scheduler
+    assert torch.equal(LTX2Scheduler().execute(10, latent=torch.zeros(1, 128, 5, 16, 16)), ltx2_scheduler(10, 1280))
+
+
+def test_tiling_host_logic_known_answers():
+    # reference tests/test_vae_streaming.py:223-297
+    from mlx_video_amd.video_vae import (TilingConfig, compute_trapezoidal_mask_1d, split_in_spatial, split_in_temporal)
+    from oracle import vae as OV
+    for length in (16, 32, 64, 128):
+        for ramp in (0, 4, 8, 16):
+            if ramp < length:
+                mk = compute_trapezoidal_mask_1d(length, ramp, ramp, False)
+                assert float(mk.min()) >= 0 and float(mk.max()) <= 1
+                assert torch.equal(mk, OV.trapezoid_mask(length, ramp, ramp, False))
+    mk = compute_trapezoidal_mask_1d(32, 8, 8, False)
+    assert torch.allclose(mk[12:20], torch.ones(8)) and bool((mk[:8].diff() >= 0).all()) and bool((mk[-8:].diff() <= 0).all())
+    assert float(compute_trapezoidal_mask_1d(32, 8, 0, True)[0]) == 0.0 and float(compute_trapezoidal_mask_1d(32, 8, 0, False)[0]) > 0.0
+    d = TilingConfig.default()
+    assert d.spatial_config.tile_size_in_pixels == 512 and d.temporal_config.tile_size_in_frames == 64
+    assert TilingConfig.aggressive().spatial_config.tile_size_in_pixels == 256 and TilingConfig.aggressive().temporal_config.tile_size_in_frames == 32
+    assert TilingConfig.conservative().spatial_config.tile_size_in_pixels == 768 and TilingConfig.conservative().temporal_config.tile_size_in_frames == 96
+    assert TilingConfig.auto(256, 256, 33) is None and TilingConfig.auto(512, 512, 33) is None
+    assert TilingConfig.auto(1024, 768, 145) is not None
+    a = TilingConfig.auto(512, 512, 97)          # config 4: temporal 64f / 24f overlap only
+    assert a.spatial_config is None and (a.temporal_config.tile_size_in_frames, a.temporal_config.tile_overlap_in_frames) == (64, 24)
+    a = TilingConfig.auto(768, 768, 65)          # configs 3/5: spatial 384px / 64px overlap only
+    assert a.temporal_config is None and (a.spatial_config.tile_size_in_pixels, a.spatial_config.tile_overlap_in_pixels) == (384, 64)
+    with pytest.raises(ValueError):
+        TilingConfig.spatial_only(48, 0)
+    iv = split_in_temporal(4, 1, 12)             # 12 latent frames, 32f tiles / 8f overlap (the 89-frame case)
+    assert iv.starts == OV.split_temporal(4, 1, 12)[0] and iv.ends[-1] == 12 and iv.starts[0] == 0
+    assert split_in_spatial(16, 2, 24).starts == OV.split_spatial(16, 2, 24)[0]
