@@ -61,10 +61,20 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 __device__ __forceinline__ void map_tile(int bid, int RT, int CT, int& rt, int& ct) {
   if ((CT & 15) == 0) {
     const int xcd = bid & 7, idx = bid >> 3;
-    const int cpx = CT >> 3;
-    const int pair = idx / (2 * RT), j = idx - pair * 2 * RT;
-    rt = j >> 1;
-    ct = xcd * cpx + pair * 2 + (j & 1);
+    const int cpx = CT >> 3;                 // column tiles owned by this XCD
+    if ((cpx & 7) == 0 && (RT & 7) == 0) {
+      // 8 row tiles x 4 column tiles per 32-workgroup round: least L2->fabric traffic per round
+      // (8*a + 4*w panel bytes against 16*a + 2*w), see profiles/r01_pmc_traffic.md
+      const int per_cg = 4 * RT;             // workgroups per column group (all row tiles)
+      const int cg = idx / per_cg, j = idx - cg * per_cg;
+      const int rg = j >> 5, k = j & 31;     // row group of 8, position inside the 8x4 patch
+      rt = rg * 8 + (k >> 2);
+      ct = xcd * cpx + cg * 4 + (k & 3);
+    } else {
+      const int pair = idx / (2 * RT), j = idx - pair * 2 * RT;
+      rt = j >> 1;
+      ct = xcd * cpx + pair * 2 + (j & 1);
+    }
   } else {
     rt = bid % RT;
     ct = bid / RT;
