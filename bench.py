@@ -77,6 +77,7 @@ def main() -> None:
     ap.add_argument("--shard", choices=["seeds", "cfgpair"], default="seeds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured step graph")
     ap.add_argument("--cache-context", action="store_true", help="reuse ctx K/V across steps (reported separately)")
     args = ap.parse_args()
 
@@ -117,21 +118,24 @@ def main() -> None:
         from mlx_video_amd.sharding import CfgPairSharding
         pg_shard = CfgPairSharding(dist, rank, world)
 
-    def run_steps(k: int, start: int = 0):
-        # k consecutive steps of the 40-step schedule (sigma values only select scalars; cost is step-invariant)
+    graph_cache = {}
+
+    def run_steps(k: int, start: int = 0, graph: bool = True):
+        # k consecutive steps of the 40-step schedule (sigma values only select scalars; cost is step-invariant).
+        # The step is replayed from one captured hipGraph (built during warm-up, like the reference's
+        # mx.compile'd step_fn, generate.py:1109-1177); every kernel still runs every step.
         s = sig_all[start:start + k + 1].clone()
         if pg_shard is not None:
             return pg_shard.denoise_dev(latents, positions, ctx_pos, ctx_neg, model, s, cfg_scale=4.0)
         return denoise_dev(latents, positions, ctx_pos, ctx_neg, model, s, cfg_scale=4.0, compile_step=True,
-                           cfg_batch=True)
+                           cfg_batch=True, use_graph=graph and not args.no_graph, graph_cache=graph_cache)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        run_steps(args.warmup)
+    run_steps(max(args.warmup, 1) if not args.no_graph else args.warmup)      # W untimed steps (>= 1: builds the step graph)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks ----
     barrier()
     t0 = time.perf_counter()
@@ -150,7 +154,7 @@ def main() -> None:
     ops.TIMER = ops.KernelTimer()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    run_steps(args.steps, start=min(args.warmup, 40 - args.steps))
+    run_steps(args.steps, start=min(args.warmup, 40 - args.steps), graph=False)
     torch.cuda.synchronize()
     dt_instr = time.perf_counter() - t1
     timer, ops.TIMER = ops.TIMER, None
@@ -171,7 +175,7 @@ def main() -> None:
         "config": {"workload": f"LTX-2 19B dev {args.width}x{args.height}x{args.frames}, CFG 4.0, cfg_batch, "
                                f"N={N} tokens, L={args.layers}, ctx 1024x3840, {args.shard} sharding",
                    "global_batch": seeds, "tokens": N, "parallelism": f"{args.shard}{world}",
-                   "ctx_kv_cached": bool(args.cache_context)},
+                   "ctx_kv_cached": bool(args.cache_context), "step_graph": not args.no_graph},
     }
     step_flops = dit_forward_flops(N, B=2, L=args.layers)
     result["step_tflop"] = step_flops / 1e12

@@ -145,6 +145,12 @@ int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent
                         const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
                         float cfg_scale, float sigma, float sigma_next, void* stream);
 
+/* Same step tail with {sigma, sigma_next} read from DEVICE memory (2 floats): lets one captured
+ * hipGraph of the whole denoise step be replayed for every step of the schedule.           */
+int ltxk_cfg_euler_step_dev(const void* v_pos, const void* v_neg, const void* latent, void* out,
+                            const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
+                            float cfg_scale, const float* sigmas_dev, void* stream);
+
 /* Euler update alone (eager path, generate.py:1293-1301, with un-rounded float sigmas):
  * out = bf16(x0 + sigma_next*(x - x0)/sigma) in fp32; n elements, any layout.             */
 int ltxk_euler_step(const void* latent, const void* denoised, void* out, int64_t n,

@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libltxk.so")
+LIB_PATH = os.environ.get("LTXK_LIB", os.path.join(_HERE, "libltxk.so"))
 
 
 class LtxkError(RuntimeError):
@@ -72,6 +72,8 @@ SIGNATURES = {
     "ltxk_tile_blend_accum": (c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 8 + [c_void_p]),
     "ltxk_tile_blend_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
     "ltxk_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ltxk_cfg_euler_step_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                          c_int32, c_float, c_void_p, c_void_p]),
     "ltxk_cfg_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                       c_int32, c_float, c_float, c_float, c_void_p]),
 }

@@ -236,7 +236,12 @@ __global__ void latent_to_tokens_kernel(const bf16* __restrict__ lat, bf16* __re
 __global__ void cfg_euler_kernel(const bf16* __restrict__ vp, const bf16* __restrict__ vn,
                                  const bf16* __restrict__ lat, bf16* __restrict__ out,
                                  const bf16* __restrict__ clean, const float* __restrict__ mask,
-                                 int B, int C, int S, float cfg, float sigma, float sigma_next) {
+                                 int B, int C, int S, float cfg, float sigma, float sigma_next,
+                                 const float* __restrict__ sig_dev) {
+  if (sig_dev) {            // graph replay: the two scalars live in device memory
+    sigma = sig_dev[0];
+    sigma_next = sig_dev[1];
+  }
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   const int cg = blockIdx.y, b = blockIdx.z;
   if (s >= S) return;
@@ -391,15 +396,30 @@ extern "C" int ltxk_latent_to_tokens(const void* latent, void* tokens, int32_t B
   return LTXK_OK;
 }
 
+static int cfg_euler_launch(const void* v_pos, const void* v_neg, const void* latent, void* out, const void* clean,
+                            const float* mask, int32_t B, int32_t C, int32_t S, float cfg_scale, float sigma,
+                            float sigma_next, const float* sig_dev, void* stream, const char* name) {
+  LTXK_CHECK_ARG(v_pos && latent && out && B > 0 && S > 0 && C > 0 && C % 8 == 0, "%s: bad arguments", name);
+  LTXK_CHECK_ARG((clean == nullptr) == (mask == nullptr), "%s: clean and mask must both be set or both NULL", name);
+  LTXK_CHECK_ARG(sig_dev != nullptr || sigma > 0.f, "%s: sigma must be > 0", name);
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((S + 63) / 64, C / 8, B), dim3(64), 0, (hipStream_t)stream,
+                     (const bf16*)v_pos, (const bf16*)v_neg, (const bf16*)latent, (bf16*)out, (const bf16*)clean, mask,
+                     B, C, S, cfg_scale, sigma, sigma_next, sig_dev);
+  LTXK_CHECK_LAUNCH(name);
+  return LTXK_OK;
+}
+
 extern "C" int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent, void* out,
                                    const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
                                    float cfg_scale, float sigma, float sigma_next, void* stream) {
-  LTXK_CHECK_ARG(v_pos && latent && out && B > 0 && S > 0 && C > 0 && C % 8 == 0, "ltxk_cfg_euler_step: bad arguments");
-  LTXK_CHECK_ARG((clean == nullptr) == (mask == nullptr), "ltxk_cfg_euler_step: clean and mask must both be set or both NULL");
-  LTXK_CHECK_ARG(sigma > 0.f, "ltxk_cfg_euler_step: sigma must be > 0");
-  hipLaunchKernelGGL(cfg_euler_kernel, dim3((S + 63) / 64, C / 8, B), dim3(64), 0, (hipStream_t)stream,
-                     (const bf16*)v_pos, (const bf16*)v_neg, (const bf16*)latent, (bf16*)out, (const bf16*)clean, mask,
-                     B, C, S, cfg_scale, sigma, sigma_next);
-  LTXK_CHECK_LAUNCH("ltxk_cfg_euler_step");
-  return LTXK_OK;
+  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, sigma, sigma_next, nullptr, stream,
+                          "ltxk_cfg_euler_step");
+}
+
+extern "C" int ltxk_cfg_euler_step_dev(const void* v_pos, const void* v_neg, const void* latent, void* out,
+                                       const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
+                                       float cfg_scale, const float* sigmas_dev, void* stream) {
+  LTXK_CHECK_ARG(sigmas_dev != nullptr, "ltxk_cfg_euler_step_dev: null sigmas_dev");
+  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, 1.f, 0.f, sigmas_dev, stream,
+                          "ltxk_cfg_euler_step_dev");
 }

@@ -177,9 +177,13 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
 // registers), so they execute while the first fragment reads of the new stage are in flight: the
 // LDS cold start after each barrier (all 8 waves reading at once) no longer idles the matrix pipe.
 // Requires TT >= 2 (both deferred groups then share the ks=1 W fragments).
+#ifndef LTXK_PREFETCH_GROUPS
+#define LTXK_PREFETCH_GROUPS 2
+#endif
 template <int TT, int WN, bool SWAP>
 struct MmaPipe {
   using G = GemmGeom<TT, WN>;
+  static constexpr int PD = LTXK_PREFETCH_GROUPS;   // fragment reads run PD MFMA groups ahead of their use
   static constexpr int NG = 2 * TT;
   static constexpr int MAXP = G::W_PER_WAVE + G::MAXA;
   static constexpr int PPG = (MAXP + NG - 1) / NG;
@@ -219,12 +223,12 @@ struct MmaPipe {
       if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
       else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
     };
-    auto need = [](int g) { return (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
+    auto need = [](int g) { return g >= NG ? TOTAL : (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
     int issued = 0;
     // virtual groups -2, -1 = the two groups deferred from the previous K-step
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
-      const int target = need(v);           // reads needed by real group v (two groups ahead)
+      const int target = need(v - 2 + PD);  // reads needed PD groups ahead
 #pragma unroll
       for (int i = 0; i < TOTAL; ++i)
         if (i >= issued && i < target) rd(i);
@@ -236,11 +240,11 @@ struct MmaPipe {
     }
 #pragma unroll
     for (int g = 0; g < NG - 2; ++g) {
-      const int target = need(g + 2);
+      const int target = need(g + PD);
 #pragma unroll
       for (int i = 0; i < TOTAL; ++i)
         if (i >= issued && i < target) rd(i);
-      issued = target;
+      issued = target > issued ? target : issued;
 #pragma unroll
       for (int q = 0; q < PPG; ++q) issue((g + 2) * PPG + q);
       group(af[g / TT][g % TT], wf[g / TT], acc[g % TT]);

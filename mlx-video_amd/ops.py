@@ -194,13 +194,19 @@ def latent_to_tokens(latent: torch.Tensor, rep: int = 1) -> torch.Tensor:
 
 def cfg_euler_step(v_pos: torch.Tensor, v_neg: Optional[torch.Tensor], latent: torch.Tensor, cfg_scale: float,
                    sigma: float, sigma_next: float, clean: Optional[torch.Tensor] = None,
-                   mask_tok: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """v_* (B,S,C) tokens; latent (B,C,...) channels-first; mask_tok (B,S) float32."""
+                   mask_tok: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                   sigmas_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """v_* (B,S,C) tokens; latent (B,C,...) channels-first; mask_tok (B,S) float32.  With ``sigmas_dev`` (2
+    float32 on the device) the scalars are read from device memory (hipGraph replay)."""
     _req(latent, BF16, "cfg_euler_step.latent")
     B, C = latent.shape[:2]
     S = latent.numel() // (B * C)
     if out is None:
         out = torch.empty_like(latent)
+    if sigmas_dev is not None:
+        check(_lib.load().ltxk_cfg_euler_step_dev(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
+                                                  B, C, S, cfg_scale, _p(sigmas_dev), _stream()), "ltxk_cfg_euler_step_dev")
+        return out
     check(_lib.load().ltxk_cfg_euler_step(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
                                           B, C, S, cfg_scale, sigma, sigma_next, _stream()), "ltxk_cfg_euler_step")
     return out

@@ -123,3 +123,30 @@ def test_denoise_dev_loop(dev, cfg_batch, compile_step, conditioned):
     assert rel_l2(out, ref) < 2e-2
     if conditioned:   # fully conditioned frame must come back as the clean latent exactly
         assert torch.equal(out[:, :, 0].cpu(), clean[:, :, 0])
+
+
+@pytest.mark.parametrize("conditioned", [False, True])
+def test_denoise_graph_replay_is_bit_identical(dev, conditioned):
+    """The captured-hipGraph loop and the eager loop must agree bit for bit over a multi-step schedule."""
+    from mlx_video_amd.conditioning import LatentState
+    from mlx_video_amd.denoise import denoise_dev
+    from mlx_video_amd.schedulers import create_position_grid, ltx2_scheduler
+    cfg = _small_cfg()
+    W = O.make_weights(cfg, seed=14)
+    model = _model(cfg, dict(W), dev)
+    g = torch.Generator().manual_seed(45)
+    lat = torch.randn(1, 128, 2, 4, 4, generator=g).to(BF)
+    cp = torch.randn(1, 64, cfg.caption_channels, generator=g).to(BF)
+    cn = torch.randn(1, 64, cfg.caption_channels, generator=g).to(BF)
+    sig = ltx2_scheduler(5, 32)
+    pos = create_position_grid(1, 2, 4, 4)
+    state = None
+    if conditioned:
+        mask = torch.ones(1, 1, 2, 1, 1)
+        mask[:, :, 0] = 0.25
+        state = LatentState(lat.to(dev), torch.randn(1, 128, 2, 4, 4, generator=g).to(BF).to(dev), mask.to(BF).to(dev))
+    kw = dict(cfg_scale=4.0, state=state, compile_step=True, cfg_batch=True)
+    eager = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig, **kw)
+    graph = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig, use_graph=True, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, graph)
