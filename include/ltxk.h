@@ -172,6 +172,11 @@ typedef struct ltxk_conv3d_args {
   int32_t causal;        /* temporal halo: 1 = 2x first frame; 0 = first + last (convolution.py:126-137);
                           * 2 = zeros on both sides (plain Conv3d padding=1 of the latent upsampler, upsampler.py:6-62) */
   int32_t pad_mode;      /* spatial halo: LTXK_PAD_ZEROS | LTXK_PAD_REFLECT (convolution.py:143-157) */
+  /* optional caller-owned fp32 scratch for split-K on small volumes (the decoder's 1024/512-channel stages
+   * have too few voxels to fill 256 CUs): S*M*Cout*4 bytes are used if they fit; NULL disables split-K.
+   * Partial slabs are written with plain stores and summed in slice order, so results are deterministic. */
+  void* workspace;
+  int64_t workspace_bytes;
 } ltxk_conv3d_args;
 
 /* nn.Conv3d 3x3x3 stride 1 inside CausalConv3d (convolution.py:78-222) as implicit GEMM.   */

@@ -31,6 +31,7 @@ class Conv3dArgs(Structure):
         ("B", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
         ("Cin", c_int32), ("Cout", c_int32),
         ("causal", c_int32), ("pad_mode", c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 

@@ -18,9 +18,11 @@ struct ConvParams {
   int B, D, H, W, Cin, Cout;
   int causal, pad_mode;
   int M, RT, CT, cpb;   // cpb = Cin/64 K-steps per tap
+  float* slab;          // split-K: fp32 partial slabs [S][M][Cout] (plain stores, summed in slice order)
+  int S, kper;          // K slices per tile, K-steps per slice
 };
 
-template <int TT, int WN, bool RES>
+template <int TT, int WN, bool RES, bool SPLIT>
 __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   using G = GemmGeom<TT, WN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -28,7 +30,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int ct = blockIdx.x % p.CT, rt = blockIdx.x / p.CT;
+  const int tile = SPLIT ? blockIdx.x / p.S : blockIdx.x;
+  const int slice = SPLIT ? blockIdx.x - tile * p.S : 0;
+  const int ct = tile % p.CT, rt = tile / p.CT;
   const int m0 = rt * G::BM, n0 = ct * G::BN;
   const int K = 27 * p.Cin;
 
@@ -127,20 +131,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = 27 * p.cpb;
-  // prologue: stages 0 and 1 (both in tap 0 unless cpb == 1)
-  int ptap = 0, pcb = 0;                 // (tap, channel block) of the prefetch stream
-  set_tap(0);
+  // this workgroup's K-step range [kbeg, nk) (the whole K unless split)
+  const int nk_all = 27 * p.cpb;
+  const int kbeg = SPLIT ? slice * p.kper : 0;
+  int nk = SPLIT ? kbeg + p.kper : nk_all;
+  nk = nk < nk_all ? nk : nk_all;
+  // prologue: stages kbeg and kbeg+1
+  int ptap = kbeg / p.cpb, pcb = kbeg - ptap * p.cpb;       // (tap, channel block) of the prefetch stream
+  set_tap(ptap);
 #pragma unroll
-  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0, 0);
-  pcb = 1;
-  if (pcb == p.cpb) { pcb = 0; ptap = 1; set_tap(1); }
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, kbeg, pcb, 0);
+  if (kbeg + 1 < nk) {
+    ++pcb;
+    if (pcb == p.cpb) { pcb = 0; ++ptap; set_tap(ptap); }
+  }
 #pragma unroll
-  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 1, pcb, 1);
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, kbeg + 1 < nk ? kbeg + 1 : kbeg, pcb, 1);
   int s = 0;
   MmaPipe<TT, WN, false> pipe;
   pipe.init();
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kbeg; kt < nk; ++kt) {
     wait_stage_and_barrier(PER_STAGE);
     int s2 = s + 2;
     s2 = s2 >= 3 ? s2 - 3 : s2;
@@ -169,6 +179,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + nq;
       if (n >= p.Cout) continue;
+      if constexpr (SPLIT) {
+        *(f32x4*)(p.slab + ((size_t)slice * p.M + m) * p.Cout + n) = acc[tt][nt];
+        continue;
+      }
       const bf16x4 b = *(const bf16x4*)(p.bias + n);
       float y[4];
 #pragma unroll
@@ -186,10 +200,69 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   }
 }
 
+// split-K finalize: out = bf16(bf16(sum_s slab[s] + bias) [+ resid]), slabs summed in slice order (deterministic)
+__global__ void conv_splitk_finalize_kernel(const float* __restrict__ slab, const bf16* __restrict__ bias,
+                                            const bf16* __restrict__ resid, bf16* __restrict__ out, int M, int Cout, int S) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // one thread per 4 outputs
+  const size_t total = (size_t)M * Cout / 4;
+  if (idx >= total) return;
+  const size_t e = idx * 4;
+  const int n = (int)(e % Cout);
+  f32x4 a = *(const f32x4*)(slab + e);
+  for (int s = 1; s < S; ++s) {
+    const f32x4 b = *(const f32x4*)(slab + (size_t)s * M * Cout + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += b[j];
+  }
+  const bf16x4 bs = *(const bf16x4*)(bias + n);
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float y = rbf(a[j] + (float)bs[j]);
+    if (resid) y = y + (float)resid[e + j];
+    o[j] = (bf16)y;
+  }
+  *(bf16x4*)(out + e) = o;
+}
+
 template <int TT, int WN, bool RES>
-static int conv_launch(const ConvParams& p, hipStream_t stream) {
+static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspace, size_t workspace_bytes) {
   using G = GemmGeom<TT, WN>;
-  auto kern = conv3d_k3_kernel<TT, WN, RES>;
+  ConvParams p = p0;
+  p.RT = (p.M + G::BM - 1) / G::BM;
+  p.CT = (p.Cout + G::BN - 1) / G::BN;
+  const int tiles = p.RT * p.CT, nk = 27 * p.cpb;
+  // split K when the tile grid leaves most of the 256 CUs idle (the 1024/512-channel stages of the decoder
+  // have only 1280 / 9216 voxels): S slices of >= 16 K-steps, fp32 slabs in the caller's workspace.
+  int S = 1;
+  if (workspace && tiles <= 128) {
+    S = 256 / tiles;
+    if (S > nk / 16) S = nk / 16;
+    const size_t per = (size_t)p.M * p.Cout * sizeof(float);
+    if ((size_t)S * per > workspace_bytes) S = (int)(workspace_bytes / per);
+    if (S > 16) S = 16;
+  }
+  if (S >= 2) {
+    auto kern = conv3d_k3_kernel<TT, WN, false, true>;
+    static thread_local int attr_dev_s = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != attr_dev_s) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+      if (e != hipSuccess) { ltxk_set_error("ltxk_conv3d_k3_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
+      attr_dev_s = dev;
+    }
+    p.slab = workspace; p.S = S; p.kper = (nk + S - 1) / S;
+    p.S = (nk + p.kper - 1) / p.kper;                      // drop empty trailing slices
+    hipLaunchKernelGGL(kern, dim3(tiles * p.S), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
+    LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16(split-K)");
+    const size_t total = (size_t)p.M * p.Cout / 4;
+    hipLaunchKernelGGL(conv_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)workspace, p.bias, p.resid, p.out, p.M, p.Cout, p.S);
+    LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16(finalize)");
+    return LTXK_OK;
+  }
+  auto kern = conv3d_k3_kernel<TT, WN, RES, false>;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -201,10 +274,8 @@ static int conv_launch(const ConvParams& p, hipStream_t stream) {
     }
     attr_dev = dev;
   }
-  ConvParams q = p;
-  q.RT = (p.M + G::BM - 1) / G::BM;
-  q.CT = (p.Cout + G::BN - 1) / G::BN;
-  hipLaunchKernelGGL(kern, dim3(q.RT * q.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, q);
+  p.slab = nullptr; p.S = 1; p.kper = nk;
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
   LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16");
   return LTXK_OK;
 }
@@ -229,8 +300,11 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.causal = a->causal; p.pad_mode = a->pad_mode; p.M = (int)M; p.cpb = a->Cin / 64; p.RT = p.CT = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool res = a->resid != nullptr;
+  float* ws = (float*)a->workspace;
+  const size_t wsb = a->workspace ? (size_t)a->workspace_bytes : 0;
+  LTXK_CHECK_ARG(((uintptr_t)ws & 15) == 0, "ltxk_conv3d_k3_bf16: workspace must be 16-byte aligned");
   if (a->Cout <= 128) {       // 256x128 tile: no wasted MFMA columns on the 128-channel stage
-    return res ? conv_launch<4, 2, true>(p, st) : conv_launch<4, 2, false>(p, st);
+    return res ? conv_launch<4, 2, true>(p, st, ws, wsb) : conv_launch<4, 2, false>(p, st, ws, wsb);
   }
-  return res ? conv_launch<5, 4, true>(p, st) : conv_launch<5, 4, false>(p, st);
+  return res ? conv_launch<5, 4, true>(p, st, ws, wsb) : conv_launch<5, 4, false>(p, st, ws, wsb);
 }

@@ -35,6 +35,17 @@ def _stream():
 
 
 _ZERO_PAGES: Dict[int, torch.Tensor] = {}
+_WORKSPACES: Dict[int, torch.Tensor] = {}
+SPLITK_WORKSPACE_BYTES = 96 << 20
+
+
+def _workspace(dev) -> torch.Tensor:
+    """Per-device fp32 scratch handed to the conv kernel for split-K (caller-owned, reused by every call
+    on the stream; the library never allocates)."""
+    key = dev.index if dev.index is not None else 0
+    if key not in _WORKSPACES:
+        _WORKSPACES[key] = torch.empty(SPLITK_WORKSPACE_BYTES // 4, dtype=torch.float32, device=dev)
+    return _WORKSPACES[key]
 
 
 def _zero_page(dev) -> torch.Tensor:
@@ -56,6 +67,8 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, causal: bool, pad_
     a.zero_page = _p(_zero_page(x.device))
     a.B, a.D, a.H, a.W, a.Cin, a.Cout = B, D, H, W, Cin, Cout
     a.causal, a.pad_mode = int(causal), pad_mode
+    ws = _workspace(x.device)
+    a.workspace, a.workspace_bytes = _p(ws), ws.numel() * 4
     V = B * D * H * W
     with ops._timed("conv3d_k3", 2.0 * 27 * Cin * Cout * V, 2.0 * V * (Cin + Cout) + 2.0 * 27 * Cin * Cout):
         check(_lib.load().ltxk_conv3d_k3_bf16(ctypes.byref(a), _stream()), "ltxk_conv3d_k3_bf16")
