@@ -22,6 +22,7 @@ namespace ltxk {
 constexpr int FA_QW = 32;         // query rows per wave
 constexpr int FA_BK = 64;         // keys per tile
 constexpr int FA_DH = 128;
+constexpr float FA_DEFER = 6.0f;   // defer the online-softmax rescale while the row max grows < 2^6
 constexpr int FA_K_BYTES = FA_BK * FA_DH * 2;    // 16 KiB: [64 keys][256 B]
 constexpr int FA_V_BYTES = FA_DH * FA_BK * 2;    // 16 KiB: [128 d][128 B]
 constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES;
@@ -34,10 +35,7 @@ struct FaParams {
   float c;   // scale * log2(e)
 };
 
-__device__ __forceinline__ void fa_glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
+__device__ __forceinline__ void fa_glds16(const void* g, void* l) { glds16(g, l); }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -73,24 +71,26 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
   const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
   const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
 
-  auto issue = [&](int t, int st) {
-    char* sk = smem + st * FA_STAGE;
-    char* sv = sk + FA_K_BYTES;
-    const int key0 = t * FA_BK;
-    // 16 K pieces + 16 V^T pieces, dealt round-robin over the NW waves (wave-uniform trip count)
-    for (int piece = wave; piece < 16; piece += NW) {
+  // i-th K / V^T LDS-DMA piece of this wave for tile t (pieces dealt round-robin over the NW waves; a wave
+  // with no i-th piece issues nothing: trip counts are wave-uniform)
+  auto issue_k = [&](int i, int t, int st) __attribute__((always_inline)) {
+    const int piece = wave + i * NW;
+    if (piece < 16) {
       const int row = piece * 4 + k_lrow;               // key within tile
-      int key = key0 + row;
+      int key = t * FA_BK + row;
       key = key < p.Tk ? key : p.Tk - 1;
-      const int chunk = k_slot ^ (row & 15);
-      fa_glds16(kbase + (size_t)key * p.ldk + chunk * 8, sk + piece * 1024);
-    }
-    for (int piece = wave; piece < 16; piece += NW) {
-      const int d = piece * 8 + v_lrow;
-      const int chunk = v_slot ^ ((d >> 1) & 7);
-      fa_glds16(vbase + (size_t)d * p.ldvt + key0 + chunk * 8, sv + piece * 1024);
+      glds16(kbase + (size_t)key * p.ldk + (k_slot ^ (row & 15)) * 8, smem + st * FA_STAGE + piece * 1024);
     }
   };
+  auto issue_v = [&](int i, int t, int st) __attribute__((always_inline)) {
+    const int piece = wave + i * NW;
+    if (piece < 16) {
+      const int d = piece * 8 + v_lrow;
+      glds16(vbase + (size_t)d * p.ldvt + t * FA_BK + (v_slot ^ ((d >> 1) & 7)) * 8,
+             smem + st * FA_STAGE + FA_K_BYTES + piece * 1024);
+    }
+  };
+  constexpr int NPW = (16 + NW - 1) / NW;               // pieces per wave per operand (4)
 
   f32x16 o[4];
 #pragma unroll
@@ -100,14 +100,16 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
   float m_run = -1e30f, l_run = 0.f;
 
   const int nt = (p.Tk + FA_BK - 1) / FA_BK;
-  issue(0, 0);
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) { issue_k(i, 0, 0); issue_v(i, 0, 0); }
   for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool pre = t + 1 < nt;
+    const int tn = pre ? t + 1 : t, stn = (t + 1) & 1;   // last tile: harmless re-load into the free slot
     const char* sk = smem + (t & 1) * FA_STAGE;
     const char* sv = sk + FA_K_BYTES;
 
-    // ---- S^T = K . Q^T ----
+    // ---- S^T = K . Q^T ; the next tile's K pieces are issued between the MFMAs (not as a burst) ----
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
       for (int ks = 0; ks < 8; ++ks) {
         const int chunk = ks * 2 + hh;
         const bf16x8 kf = *(const bf16x8*)(sk + row * 256 + ((chunk ^ (row & 15)) << 4));
+        if ((ks & 3) == 1) issue_k(kb * 2 + (ks >> 2), tn, stn);
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
       }
     }
@@ -139,10 +142,22 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kb][j]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-    const float mc = m_new * p.c;
-    m_run = m_new;
+    // Deferred rescale: the running max is only raised (and O, l rescaled: 65 VALU ops per lane) when some
+    // row's max grew by more than 2^FA_DEFER in the exponent domain; otherwise P is taken against the old
+    // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
+    // tile's P is exponentiated after the decision and the previous tile's P.V is complete, so everything
+    // scaled against the old max is rescaled exactly once.
+    if (__any((mx - m_run) * p.c > FA_DEFER)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
+    }
+    const float mc = m_run * p.c;
     float psum = 0.f;
     bf16x8 pb[2][2];
 #pragma unroll
@@ -153,11 +168,7 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
         psum += e;
         pb[kb][j >> 3][j & 7] = (bf16)e;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T . P^T ; V^T fragment element j of half hh = key 16s + 8(j>>2) + 4hh + (j&3)
 #pragma unroll
@@ -175,10 +186,12 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
           bf16x8 vf;
           vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
           vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+          if (kb == 0 && sidx == 1) issue_v(db, tn, stn);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][sidx], o[db], 0, 0, 0);
         }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -299,10 +312,22 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel_v2(FaParams p) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kb][j]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-    const float mc = m_new * p.c;
-    m_run = m_new;
+    // Deferred rescale: the running max is only raised (and O, l rescaled: 65 VALU ops per lane) when some
+    // row's max grew by more than 2^FA_DEFER in the exponent domain; otherwise P is taken against the old
+    // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
+    // tile's P is exponentiated after the decision and the previous tile's P.V is complete, so everything
+    // scaled against the old max is rescaled exactly once.
+    if (__any((mx - m_run) * p.c > FA_DEFER)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
+    }
+    const float mc = m_run * p.c;
     float psum = 0.f;
     bf16x8 pb[2][2];
 #pragma unroll
@@ -313,11 +338,7 @@ __global__ __launch_bounds__(256, 3) void flash_attn_kernel_v2(FaParams p) {
         psum += e;
         pb[kb][j >> 3][j & 7] = (bf16)e;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
+    l_run += psum;
 
     // (B) V(t) has landed in every wave's share (the K(t+1) pieces, issued after it, may still fly)
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");

@@ -56,6 +56,22 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// LDS-DMA of one 1-KiB piece: lane i's 16 bytes at gsrc land at lds_dst + 16*i (lds_dst wave-uniform).
+// Issued as inline asm on purpose: hipcc (ROCm 7.2) models the builtin as a FLAT access that may
+// touch LDS, which degrades every later ds_read wait in the loop to `s_waitcnt lgkmcnt(0)` — the
+// fragment prefetch two MFMA groups ahead would then be drained at each use.  Hidden in asm, the
+// compiler emits counted lgkmcnt waits for its ds_reads; the DMA itself is retired by the counted
+// vmcnt in wait_stage_and_barrier().  M0 (the DMA's LDS base) is written and restored inside the
+// one statement that uses it.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst)
+               : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -81,72 +81,68 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
 
 // ---------------------------------------------------------------------------------------
 // q/k RMSNorm (full inner dim, learned weight) + SPLIT RoPE, in place.
-// Lane map: a wave pass covers 4 heads; 16 lanes per head; lane handles x1 = [j0,j0+4) of the
-// first half and x2 = the same offsets of the second half (the rotation partners).
+// One wave per (row, segment).  Lane map: a wave pass covers 8 heads; 8 lanes per head; lane holds
+// x1 = [j0, j0+8) of the head's first half and x2 = the same offsets of the second half (the rotation
+// partners), so every access is a 16-byte vector and each 8-lane group touches whole 128-byte lines.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(
     bf16* __restrict__ buf, int ld, int M, int nseg, int D, const bf16* __restrict__ weight,
     const float* __restrict__ cosb, const float* __restrict__ sinb, int T, int H, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int item = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= M * nseg) return;
+  const int row = item / nseg, sgi = item - row * nseg;
   const int t = row % T;
-  const int npass = H >> 2;          // 4 heads per pass (H % 4 == 0), dh = 128
-  const int hl = lane >> 4;          // head within pass
-  const int j0 = (lane & 15) * 4;    // offset within the 64-wide half
-  constexpr int MAXP = 8;            // H <= 32
-  f32x4 cs[MAXP], sn[MAXP];
-  if (cosb) {
+  const int npass = (H + 7) >> 3;    // 8 heads per pass (lanes past the last head idle), dh = 128
+  const int hl = lane >> 3;          // head within pass
+  const int j0 = (lane & 7) * 8;     // offset within the 64-wide half
+  constexpr int MAXP = 4;            // H <= 32
+  bf16* xr = buf + (size_t)row * ld + (size_t)sgi * D;
+  const bf16* wr = weight + (size_t)sgi * D;
+  bf16x8 a[MAXP], b[MAXP];
+  float sq = 0.f;
 #pragma unroll
-    for (int ps = 0; ps < MAXP; ++ps)
-      if (ps < npass) {
-        const size_t off = ((size_t)(ps * 4 + hl) * T + t) * 64 + j0;
-        cs[ps] = *(const f32x4*)(cosb + off);
-        sn[ps] = *(const f32x4*)(sinb + off);
+  for (int ps = 0; ps < MAXP; ++ps)
+    if (ps < npass && ps * 8 + hl < H) {
+      const int base = (ps * 8 + hl) * 128 + j0;
+      a[ps] = *(const bf16x8*)(xr + base);
+      b[ps] = *(const bf16x8*)(xr + base + 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float fa = (float)a[ps][j], fb = (float)b[ps][j];
+        sq += fa * fa + fb * fb;
       }
-  }
-  for (int sgi = 0; sgi < nseg; ++sgi) {
-    bf16* xr = buf + (size_t)row * ld + (size_t)sgi * D;
-    const bf16* wr = weight + (size_t)sgi * D;
-    bf16x4 a[MAXP], b[MAXP];
-    float sq = 0.f;
+    }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
 #pragma unroll
-    for (int ps = 0; ps < MAXP; ++ps)
-      if (ps < npass) {
-        const int base = (ps * 4 + hl) * 128 + j0;
-        a[ps] = *(const bf16x4*)(xr + base);
-        b[ps] = *(const bf16x4*)(xr + base + 64);
+  for (int ps = 0; ps < MAXP; ++ps)
+    if (ps < npass && ps * 8 + hl < H) {
+      const int base = (ps * 8 + hl) * 128 + j0;
+      const bf16x8 wa = *(const bf16x8*)(wr + base);
+      const bf16x8 wb = *(const bf16x8*)(wr + base + 64);
+      f32x4 c0, c1, s0, s1;
+      if (cosb) {
+        const size_t off = ((size_t)(ps * 8 + hl) * T + t) * 64 + j0;
+        c0 = *(const f32x4*)(cosb + off); c1 = *(const f32x4*)(cosb + off + 4);
+        s0 = *(const f32x4*)(sinb + off); s1 = *(const f32x4*)(sinb + off + 4);
+      }
+      bf16x8 oa, ob;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float fa = (float)a[ps][j], fb = (float)b[ps][j];
-          sq += fa * fa + fb * fb;
+      for (int j = 0; j < 8; ++j) {
+        const float x1 = rbf((float)a[ps][j] * rstd * (float)wa[j]);
+        const float x2 = rbf((float)b[ps][j] * rstd * (float)wb[j]);
+        if (cosb) {
+          const float c = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
+          oa[j] = (bf16)(x1 * c - sn * x2);
+          ob[j] = (bf16)(x2 * c + sn * x1);
+        } else {
+          oa[j] = (bf16)x1;
+          ob[j] = (bf16)x2;
         }
       }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-#pragma unroll
-    for (int ps = 0; ps < MAXP; ++ps)
-      if (ps < npass) {
-        const int base = (ps * 4 + hl) * 128 + j0;
-        const bf16x4 wa = *(const bf16x4*)(wr + base);
-        const bf16x4 wb = *(const bf16x4*)(wr + base + 64);
-        bf16x4 oa, ob;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float x1 = rbf((float)a[ps][j] * rstd * (float)wa[j]);
-          const float x2 = rbf((float)b[ps][j] * rstd * (float)wb[j]);
-          if (cosb) {
-            const float c = cs[ps][j], s = sn[ps][j];
-            oa[j] = (bf16)(x1 * c - s * x2);
-            ob[j] = (bf16)(x2 * c + s * x1);
-          } else {
-            oa[j] = (bf16)x1;
-            ob[j] = (bf16)x2;
-          }
-        }
-        *(bf16x4*)(xr + base) = oa;
-        *(bf16x4*)(xr + base + 64) = ob;
-      }
-  }
+      *(bf16x8*)(xr + base) = oa;
+      *(bf16x8*)(xr + base + 64) = ob;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -334,10 +330,10 @@ extern "C" int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, 
                                 int32_t T, int32_t H, float eps, void* stream) {
   LTXK_CHECK_ARG(buf && weight && M > 0 && nseg > 0, "ltxk_qknorm_rope: null/empty input");
   LTXK_CHECK_ARG(D == H * 128 && H % 4 == 0 && H <= 32, "ltxk_qknorm_rope: need D == H*128, H %% 4 == 0, H <= 32 (D=%d H=%d)", D, H);
-  LTXK_CHECK_ARG(ld >= nseg * D && ld % 4 == 0, "ltxk_qknorm_rope: ld=%d too small", ld);
+  LTXK_CHECK_ARG(ld >= nseg * D && ld % 8 == 0 && ((uintptr_t)buf & 15) == 0, "ltxk_qknorm_rope: ld=%d must be >= nseg*D and a multiple of 8, buf 16-byte aligned", ld);
   LTXK_CHECK_ARG((cos == nullptr) == (sin == nullptr), "ltxk_qknorm_rope: cos and sin must both be set or both NULL");
   LTXK_CHECK_ARG(T > 0, "ltxk_qknorm_rope: T must be > 0");
-  const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const dim3 grid((M * nseg + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   hipLaunchKernelGGL(qknorm_rope_kernel, grid, dim3(256), 0, (hipStream_t)stream, (bf16*)buf, ld, M, nseg, D,
                      (const bf16*)weight, cos, sin, T, H, eps);
   LTXK_CHECK_LAUNCH("ltxk_qknorm_rope");
