@@ -79,33 +79,9 @@ __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
   }
 }
 
-// One K-step of MFMAs for this wave out of LDS stage `st`.
-// SWAP=false: acc tile = D[n (4 regs)][tok (lane&15)]  (W is the MFMA A operand)
-// SWAP=true : acc tile = D[tok (4 regs)][n (lane&15)]
-template <int TT, int WN, bool SWAP>
-__device__ __forceinline__ void mma_stage(const char* st, int wm, int wn, int lane,
-                                          f32x4 (&acc)[TT][4]) {
-  using G = GemmGeom<TT, WN>;
-  const char* wb = st + (wn * 64) * 128;
-  const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128;
-  const int rowoff = (lane & 15) * 128;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int koff = (((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4);
-    bf16x8 wf[4], af[TT];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(wb + nt * 2048 + rowoff + koff);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) af[tt] = *(const bf16x8*)(ab + tt * 2048 + rowoff + koff);
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[tt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt], wf[nt], acc[tt][nt], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[tt], acc[tt][nt], 0, 0, 0);
-  }
-}
-
+// Operand roles.  SWAP=false: acc tile = D[n (4 regs)][row (lane&15)]  (W is the MFMA A operand), so a lane
+// holds 4 consecutive output columns of one row: 8-byte row-major stores.  SWAP=true: acc tile =
+// D[row (4 regs)][n (lane&15)]: 4 consecutive rows of one column, used for the transposed (V^T) output.
 // Software-pipelined K-step: the 2*TT MFMA groups (4 MFMAs each: one A-row fragment x 4 W
 // fragments) run in a fixed order pinned by sched_barrier; fragment ds_read_b128s are issued two
 // groups ahead of their use, and this wave's LDS-DMA pieces of the stage two K-steps ahead are

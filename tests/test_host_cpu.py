@@ -151,3 +151,41 @@ def test_tiling_host_logic_known_answers():
     iv = split_in_temporal(4, 1, 12)             # 12 latent frames, 32f tiles / 8f overlap (the 89-frame case)
     assert iv.starts == OV.split_temporal(4, 1, 12)[0] and iv.ends[-1] == 12 and iv.starts[0] == 0
     assert split_in_spatial(16, 2, 24).starts == OV.split_spatial(16, 2, 24)[0]
+
+
+def test_media_and_checkpoint_keymaps(tmp_path):
+    import numpy as np
+    from PIL import Image
+    from safetensors.torch import save_file
+    from mlx_video_amd import media, weights
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 255, (70, 100, 3), dtype=np.uint8)).save(tmp_path / "a.png")
+    assert media.load_image(tmp_path / "a.png").shape == (64, 96, 3)                    # rounded down to /32
+    im = media.load_image(tmp_path / "a.png", 128, 160)
+    assert im.shape == (128, 160, 3) and 0.0 <= im.min() and im.max() <= 1.0
+    c = media.image_to_conditioning(im)
+    assert c.shape == (1, 3, 1, 128, 160) and -1.0 <= float(c.min()) and float(c.max()) <= 1.0
+    fr = media.load_frames(rng.integers(0, 255, (12, 32, 48, 3), dtype=np.uint8), 64, 96)
+    assert fr.shape == (12, 64, 96, 3) and media.frames_to_conditioning(fr).shape == (1, 3, 9, 64, 96)   # 12 -> 9 = 1+8k
+    # checkpoint key maps + conv layout (ltx.py:508-533, decoder.py:544-591,708-710, encoder.py:135-179)
+    sd = {"model.diffusion_model.transformer_blocks.0.attn1.to_out.0.weight": torch.zeros(4, 4),
+          "model.diffusion_model.transformer_blocks.0.ff.net.0.proj.weight": torch.zeros(8, 4),
+          "model.diffusion_model.audio_patchify_proj.weight": torch.zeros(2, 2),
+          "vae.decoder.mid_block.resnets.1.conv1.conv.weight": torch.arange(2 * 3 * 27, dtype=torch.float32).reshape(2, 3, 3, 3, 3),
+          "vae.decoder.up_blocks.1.upsamplers.0.conv.bias": torch.zeros(2),
+          "vae.decoder.up_blocks.2.resnets.4.conv2.conv.bias": torch.zeros(2),
+          "vae.per_channel_statistics.mean-of-means": torch.zeros(128),
+          "vae.per_channel_statistics.std-of-means": torch.ones(128),
+          "vae.encoder.down_blocks.0.res_blocks.1.conv1.conv.weight": torch.zeros(2, 3, 3, 3, 3)}
+    save_file(sd, str(tmp_path / "m.safetensors"), metadata={"config": '{"vae": {"timestep_conditioning": true}}'})
+    raw = weights.read_safetensors([tmp_path / "m.safetensors"])
+    tw = weights.transformer_weights(raw, "cpu")
+    assert set(tw) == {"transformer_blocks.0.attn1.to_out.weight", "transformer_blocks.0.ff.proj_in.weight"}
+    dw = weights.vae_decoder_weights(raw, "cpu")
+    assert {"up_blocks.0.res_blocks.1.conv1.conv.weight", "up_blocks.3.conv.bias", "up_blocks.6.res_blocks.4.conv2.conv.bias",
+            "latents_mean", "latents_std"} <= set(dw)
+    w = dw["up_blocks.0.res_blocks.1.conv1.conv.weight"]
+    assert w.shape == (2, 3, 3, 3, 3) and float(w[1, 2, 1, 0, 2]) == float(sd["vae.decoder.mid_block.resnets.1.conv1.conv.weight"][1, 2, 2, 1, 0])
+    ew = weights.vae_encoder_weights(raw, "cpu")
+    assert "down_blocks.0.res_blocks.1.conv1.weight" in ew and "per_channel_statistics.mean" in ew
+    assert weights.sniff_timestep_conditioning(tmp_path / "m.safetensors") is True
