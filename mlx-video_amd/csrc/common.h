@@ -46,12 +46,12 @@ __device__ __forceinline__ float rbf(float x) {
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // nn.gelu_approx: 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3)))
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1); v_exp_f32 + v_rcp_f32 (1 ulp each, far below the bf16 the result
-  // is rounded to) instead of an IEEE division: the epilogue of the FF1 GEMM is VALU-bound otherwise.
-  const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.885390081777927f * u) + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  // nn.gelu_approx: 0.5x(1+tanh(u)), u = sqrt(2/pi)(x+0.044715x^3).  0.5(1+tanh u) = 1/(1+exp(-2u)), so
+  // gelu = x * rcp(1 + exp2(x*(c1 + c2*x^2))) with c1 = -2*sqrt(2/pi)*log2(e), c2 = 0.044715*c1:
+  // 7 VALU ops (v_exp_f32 + v_rcp_f32, 1 ulp each — far below the bf16 the result is rounded to) instead of
+  // the 14 of the textbook form; the FF1 GEMM epilogue is VALU-bound.
+  const float t = __builtin_fmaf(-0.10294324f, x * x, -2.3022082f) * x;
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }

@@ -4,6 +4,10 @@
 // transformer.py:254,257,347 as epilogues.
 #include "gemm_core.h"
 
+#ifndef LTXK_STAGGER
+#define LTXK_STAGGER 0   // measured neutral (profiles/r01 notes); kept for A/B
+#endif
+
 namespace ltxk {
 
 constexpr int GEMM_BN = 256;
@@ -88,18 +92,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
   int s = 0;
   if constexpr (TT >= 2) {
-    MmaPipe<TT, 4, TRANS> pipe;
-    pipe.init();
-    for (int kt = 0; kt < nk; ++kt) {
-      // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
-      wait_stage_and_barrier(PER_STAGE);
-      int s2 = s + 2;
-      s2 = s2 >= 3 ? s2 - 3 : s2;
-      const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
-      pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
-      s = s + 1 == 3 ? 0 : s + 1;
+    auto kloop = [&](auto& pipe) __attribute__((always_inline)) {
+      pipe.init();
+      for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
+        wait_stage_and_barrier(PER_STAGE);
+        int s2 = s + 2;
+        s2 = s2 >= 3 ? s2 - 3 : s2;
+        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
+        pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+        s = s + 1 == 3 ? 0 : s + 1;
+      }
+      pipe.finish(acc);
+    };
+#if LTXK_STAGGER
+    if (wave >= 4) {                  // SIMD partners of waves 0-3 run half a K-step out of phase
+      MmaPipe<TT, 4, TRANS, TT> pipe;
+      kloop(pipe);
+    } else
+#endif
+    {
+      MmaPipe<TT, 4, TRANS, 2> pipe;
+      kloop(pipe);
     }
-    pipe.finish(acc);
   } else {
     for (int kt = 0; kt < nk; ++kt) {
       wait_stage_and_barrier(PER_STAGE);

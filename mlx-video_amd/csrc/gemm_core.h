@@ -140,7 +140,11 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
 #ifndef LTXK_PREFETCH_GROUPS
 #define LTXK_PREFETCH_GROUPS 2
 #endif
-template <int TT, int WN, bool SWAP>
+// DG = number of trailing MFMA groups of a K-step that are deferred past the next barrier (2 <= DG <= TT:
+// all deferred groups use the ks=1 W fragments).  DG=2 hides the LDS cold start; DG=TT additionally puts a
+// wave half a K-step out of phase with a DG=2 wave — used for waves 4-7, the SIMD partners of waves 0-3, so
+// that the two waves of a SIMD do not hit their LDS-read bursts, DMA issues and MFMA-dense stretches together.
+template <int TT, int WN, bool SWAP, int DG = 2>
 struct MmaPipe {
   using G = GemmGeom<TT, WN>;
   static constexpr int PD = LTXK_PREFETCH_GROUPS;   // fragment reads run PD MFMA groups ahead of their use
@@ -148,8 +152,9 @@ struct MmaPipe {
   static constexpr int MAXP = G::W_PER_WAVE + G::MAXA;
   static constexpr int PPG = (MAXP + NG - 1) / NG;
   static constexpr int TOTAL = 2 * (4 + TT);
-  // fragment registers persist across K-steps: after step() wf[1][*], af[1][TT-2], af[1][TT-1] hold the
-  // operands of the two deferred groups; the next step() consumes them before overwriting them.
+  static_assert(TT >= 2 && DG >= 2 && DG <= TT, "deferred groups must all lie in the ks=1 half");
+  // fragment registers persist across K-steps: after step() wf[1][*] and af[1][TT-DG..TT-1] hold the operands
+  // of the deferred groups; the next step() consumes them before overwriting them.
   bf16x8 wf[2][4], af[2][TT];
 
   __device__ __forceinline__ void init() {
@@ -172,7 +177,6 @@ struct MmaPipe {
 
   template <class IssueFn>
   __device__ __forceinline__ void step(const char* st, int wm, int wn, int lane, f32x4 (&acc)[TT][4], IssueFn&& issue) {
-    static_assert(TT >= 2, "rotated pipeline needs TT >= 2");
     const char* wb = st + (wn * 64) * 128 + (lane & 15) * 128;
     const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128 + (lane & 15) * 128;
     const int koff0 = (((lane >> 4)) ^ (lane & 7)) << 4;
@@ -183,38 +187,44 @@ struct MmaPipe {
       if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
       else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
     };
-    auto need = [](int g) { return g >= NG ? TOTAL : (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
+    // reads needed by real group g of THIS stage (flat order W0, A0[*], W1, A1[*]); g >= NG: everything
+    auto need = [](int g) { return g < 0 ? 0 : (g >= NG ? TOTAL : (g / TT) * (4 + TT) + 4 + (g % TT) + 1); };
     int issued = 0;
-    // virtual groups -2, -1 = the two groups deferred from the previous K-step
+    // virtual groups: the DG groups deferred from the previous K-step (operands already in registers)
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int target = need(v - 2 + PD);  // reads needed PD groups ahead
+    for (int v = 0; v < DG; ++v) {
+      int target = need(v - DG + PD);
+      if (target > 4 + TT) target = 4 + TT;          // the ks=1 registers still feed the deferred groups
 #pragma unroll
       for (int i = 0; i < TOTAL; ++i)
         if (i >= issued && i < target) rd(i);
-      issued = target;
+      issued = target > issued ? target : issued;
 #pragma unroll
       for (int q = 0; q < PPG; ++q) issue(v * PPG + q);
-      group(af[1][TT - 2 + v], wf[1], acc[TT - 2 + v]);
+      group(af[1][TT - DG + v], wf[1], acc[TT - DG + v]);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int g = 0; g < NG - 2; ++g) {
+    for (int g = 0; g < NG - DG; ++g) {
       const int target = need(g + PD);
 #pragma unroll
       for (int i = 0; i < TOTAL; ++i)
         if (i >= issued && i < target) rd(i);
       issued = target > issued ? target : issued;
 #pragma unroll
-      for (int q = 0; q < PPG; ++q) issue((g + 2) * PPG + q);
+      for (int q = 0; q < PPG; ++q) issue((g + DG) * PPG + q);
       group(af[g / TT][g % TT], wf[g / TT], acc[g % TT]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // operands of the groups deferred to the next step must leave this stage's LDS slot before the barrier
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i)
+      if (i >= issued) rd(i);
   }
 
   __device__ __forceinline__ void finish(f32x4 (&acc)[TT][4]) {
-    group(af[1][TT - 2], wf[1], acc[TT - 2]);
-    group(af[1][TT - 1], wf[1], acc[TT - 1]);
+#pragma unroll
+    for (int v = 0; v < DG; ++v) group(af[1][TT - DG + v], wf[1], acc[TT - DG + v]);
   }
 };
 
