@@ -1,0 +1,62 @@
+"""Runs the single-GPU configurations of BASELINE.json end to end with synthetic (random-init) weights and
+random text embeddings, through generate_video, and prints one JSON line per config with the phase times.
+Config 4 (8 GPUs) is the driver's scaling run of bench.py."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mlx_video_amd.generate import PipelineType, generate_video
+from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+from mlx_video_amd.upsampler import LatentUpsampler
+from mlx_video_amd.video_vae import LTX2VideoDecoder, VideoEncoder, random_decoder_weights
+from mlx_video_amd.weights import random_upsampler_weights
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+layers = int(os.environ.get("LAYERS", "48"))
+tr = LTXModel.random_init(LTXModelConfig(num_layers=layers), dev)
+dec = LTX2VideoDecoder(random_decoder_weights(dev))
+ups = LatentUpsampler(random_upsampler_weights(dev))
+g = torch.Generator(device=dev).manual_seed(1)
+emb = torch.randn((1, 1024, 3840), generator=g, device=dev).to(BF)
+neg = torch.randn((1, 1024, 3840), generator=g, device=dev).to(BF)
+
+
+def enc_weights():
+    import math
+    W = {}
+    def conv(name, o, i):
+        W[f"{name}.weight"] = (torch.randn((o, 3, 3, 3, i), generator=g, device=dev) / math.sqrt(27 * i)).to(BF)
+        W[f"{name}.bias"] = torch.zeros(o, dtype=BF, device=dev)
+    from mlx_video_amd.video_vae import ENC_BLOCKS
+    conv("conv_in", 128, 48)
+    ch = 128
+    for bi, (kind, arg) in enumerate(ENC_BLOCKS):
+        if kind == "res_x":
+            for li in range(arg):
+                conv(f"down_blocks.{bi}.res_blocks.{li}.conv1", ch, ch); conv(f"down_blocks.{bi}.res_blocks.{li}.conv2", ch, ch)
+        else:
+            conv(f"down_blocks.{bi}.conv", ch * 2 // (arg[0] * arg[1] * arg[2]), ch); ch *= 2
+    conv("conv_out", 129, ch)
+    W["per_channel_statistics.mean"] = torch.zeros(128, dtype=BF, device=dev)
+    W["per_channel_statistics.std"] = torch.ones(128, dtype=BF, device=dev)
+    return W
+
+
+enc = VideoEncoder(enc_weights())
+runs = [
+    ("config1 dev 128x128x9 1 step", dict(pipeline=PipelineType.DEV, height=128, width=128, num_frames=9, num_inference_steps=1)),
+    ("config2 dev 512x512x33 40 steps CFG4", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=33, num_inference_steps=40)),
+    ("config3 distilled 768x768x65 two-stage", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3)),
+    ("config5 ic_lora 768x768x65 video-cond", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 video_conditionings=[((torch.rand((1, 3, 65, 768, 768), generator=g, device=dev) * 2 - 1).to(BF), 0, 1.0)])),
+]
+for name, kw in runs:
+    pj = f"/tmp/prof_{abs(hash(name))}.json"
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fr = generate_video(prompt="x", transformer=tr, vae_decoder=dec, vae_encoder=enc, upsampler=ups, prompt_embeds=emb,
+                        negative_prompt_embeds=neg, cfg_scale=4.0, compile_step=True, cfg_batch=True, device=dev, seed=7,
+                        profile_json_path=pj, **kw)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ph = json.load(open(pj))["phases_s"]
+    print(json.dumps({"config": name, "frames": list(fr.shape), "wall_s": round(dt, 3), "phases_s": {k: round(v, 4) for k, v in ph.items()},
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
