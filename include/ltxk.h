@@ -201,9 +201,10 @@ int ltxk_s2d_skip(const void* conv, const void* xpad, void* out, int32_t B, int3
                   int32_t Wp, int32_t Cc, int32_t Cx, int32_t st, int32_t sh, int32_t sw, int32_t G,
                   void* stream);
 
-/* latents (B,C,S) channels-first -> (B,S,C) channels-last with fp32 x*std+mean (decoder.py:349-355). */
-int ltxk_latent_denorm_cl(const void* latent, const void* mean, const void* std, void* out,
-                          int32_t B, int32_t C, int64_t S, void* stream);
+/* latents (B,C,S) channels-first -> (B,S,C) channels-last with fp32 x*std+mean (decoder.py:349-355);
+ * noise != NULL: the timestep-conditioned decoder's blend noise*s + (1-s)*x first (decoder.py:381-385). */
+int ltxk_latent_denorm_cl(const void* latent, const void* noise, float noise_scale, const void* mean,
+                          const void* std, void* out, int32_t B, int32_t C, int64_t S, void* stream);
 
 /* (B,S,ldx>=C) channels-last -> (B,C,S) channels-first with fp32 (x-mean)/std (ops.py:94-109). */
 int ltxk_latent_norm_cf(const void* x, int32_t ldx, const void* mean, const void* std, void* out,

@@ -60,7 +60,8 @@ SIGNATURES = {
     "ltxk_d2s_add": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                c_void_p]),
     "ltxk_s2d_skip": (c_int32, [c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_void_p]),
-    "ltxk_latent_denorm_cl": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
+    "ltxk_latent_denorm_cl": (c_int32, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
+                                        c_void_p]),
     "ltxk_latent_norm_cf": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64,
                                       c_void_p]),
     "ltxk_unpatchify_cf": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,

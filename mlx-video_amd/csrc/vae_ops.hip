@@ -98,8 +98,9 @@ __global__ __launch_bounds__(256) void d2s_add_kernel(const bf16* __restrict__ c
 // latents (B,C,S) channels-first -> (B,S,C) channels-last with fp32 per-channel x*std+mean
 // (decoder.py:349-355); dir<0: (B,S,C) -> (B,C,S) with (x-mean)/std (ops.py:94-109).
 // ---------------------------------------------------------------------------------------
-__global__ void latent_denorm_cl_kernel(const bf16* __restrict__ lat, const bf16* __restrict__ mean,
-                                        const bf16* __restrict__ stdv, bf16* __restrict__ out, int B, int C, int64_t S) {
+__global__ void latent_denorm_cl_kernel(const bf16* __restrict__ lat, const bf16* __restrict__ noise, float noise_scale,
+                                        const bf16* __restrict__ mean, const bf16* __restrict__ stdv,
+                                        bf16* __restrict__ out, int B, int C, int64_t S) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int cg = blockIdx.y, b = blockIdx.z;
   if (s >= S) return;
@@ -107,7 +108,10 @@ __global__ void latent_denorm_cl_kernel(const bf16* __restrict__ lat, const bf16
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = cg * 8 + j;
-    const float x = (float)lat[((int64_t)b * C + c) * S + s];
+    const int64_t li = ((int64_t)b * C + c) * S + s;
+    float x = (float)lat[li];
+    // timestep-conditioned decode: sample = noise*s + (1-s)*sample (decoder.py:381-385), bf16 op by op
+    if (noise) x = rbf(rbf((float)noise[li] * noise_scale) + rbf((1.0f - noise_scale) * x));
     o[j] = (bf16)(x * (float)stdv[c] + (float)mean[c]);
   }
   *(bf16x8*)(out + ((int64_t)b * S + s) * C + cg * 8) = o;
@@ -386,11 +390,11 @@ extern "C" int ltxk_d2s_add(const void* conv, const void* xin, void* out, int32_
   return LTXK_OK;
 }
 
-extern "C" int ltxk_latent_denorm_cl(const void* latent, const void* mean, const void* std, void* out,
-                                     int32_t B, int32_t C, int64_t S, void* stream) {
+extern "C" int ltxk_latent_denorm_cl(const void* latent, const void* noise, float noise_scale, const void* mean,
+                                     const void* std, void* out, int32_t B, int32_t C, int64_t S, void* stream) {
   LTXK_CHECK_ARG(latent && mean && std && out && B > 0 && C > 0 && C % 8 == 0 && S > 0, "ltxk_latent_denorm_cl: bad arguments");
   hipLaunchKernelGGL(latent_denorm_cl_kernel, dim3((unsigned)((S + 63) / 64), C / 8, B), dim3(64), 0, (hipStream_t)stream,
-                     (const bf16*)latent, (const bf16*)mean, (const bf16*)std, (bf16*)out, B, C, S);
+                     (const bf16*)latent, (const bf16*)noise, noise_scale, (const bf16*)mean, (const bf16*)std, (bf16*)out, B, C, S);
   LTXK_CHECK_LAUNCH("ltxk_latent_denorm_cl");
   return LTXK_OK;
 }

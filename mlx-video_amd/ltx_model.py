@@ -351,11 +351,31 @@ class LTXModel:
 
 
 class X0Model:
-    """ltx.py:888-906: velocity -> denoised wrapper (per-token sigma = timesteps)."""
+    """ltx.py:888-906: velocity -> denoised wrapper, x0 = latent - timesteps*velocity with the per-token
+    timesteps as sigma (utils.py:404-440, fp32 then cast).  Only used by the reference's legacy
+    ltx_pipelines/utils helpers; implemented with the step kernel per distinct sigma."""
 
     def __init__(self, velocity_model: LTXModel):
         self.velocity_model = velocity_model
 
     def __call__(self, video: Optional[Modality] = None, audio: Optional[Modality] = None):
-        raise NotImplementedError("X0Model is only used by the reference's legacy ltx_pipelines/utils helpers "
-                                  "(dead code there, SURVEY.md §2a #14); use denoise.denoise_dev/denoise_distilled")
+        v, _ = self.velocity_model(video, audio)
+        if v is None:
+            return None, None
+        lat = video.latent.to(BF16)
+        B, N, C = lat.shape
+        out = torch.empty_like(lat)
+        ts = video.timesteps.to(BF16)
+        for val in torch.unique(ts).tolist():
+            # ltxk_cfg_euler_step with sigma_next = 0 returns x0 = bf16(x - sigma*v); it works on channels-first
+            # latents, so view the (B,N,C) tokens as a (B*N, C, 1) "latent" with one position per token row
+            sel = (ts == val)
+            idx = sel.reshape(-1).nonzero().squeeze(1)
+            xs = lat.reshape(B * N, C)[idx].contiguous().reshape(-1, C, 1)
+            vs = v.reshape(B * N, C)[idx].contiguous().reshape(-1, 1, C)
+            if float(val) == 0.0:
+                out.reshape(B * N, C)[idx] = xs.reshape(-1, C)
+                continue
+            x0 = ops.cfg_euler_step(vs, None, xs, 1.0, float(val), 0.0)
+            out.reshape(B * N, C)[idx] = x0.reshape(-1, C)
+        return out, None

@@ -77,7 +77,7 @@ def upsample_latents(latent: torch.Tensor, upsampler: LatentUpsampler, latent_me
     S = F * H * W
     lat = latent.to(BF16).contiguous()
     cl = torch.empty((B, S, C), dtype=BF16, device=lat.device)
-    check(lib.ltxk_latent_denorm_cl(_p(lat), _p(latent_mean), _p(latent_std), _p(cl), B, C, S, _stream()), "ltxk_latent_denorm_cl")
+    check(lib.ltxk_latent_denorm_cl(_p(lat), None, 0.0, _p(latent_mean), _p(latent_std), _p(cl), B, C, S, _stream()), "ltxk_latent_denorm_cl")
     up = upsampler(cl.reshape(B, F, H, W, C).permute(0, 4, 1, 2, 3))
     B2, C2, F2, H2, W2 = up.shape
     S2 = F2 * H2 * W2

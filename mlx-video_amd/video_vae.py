@@ -349,13 +349,14 @@ class LTX2VideoDecoder:
             if noise is None:
                 raise ValueError("timestep-conditioned decode needs an explicit `noise` tensor (the reference draws "
                                  "mx.random.normal, decoder.py:381-385; MLX's stream is not reproducible here)")
-            x = (noise.to(BF16) * self.decode_noise_scale).to(BF16) + ((1.0 - self.decode_noise_scale) * x).to(BF16)
+            nz = noise.to(BF16).contiguous()
             tval = self.decode_timestep if timestep is None else float(timestep.reshape(-1)[0])
             st = torch.full((B,), tval * 1000.0, dtype=torch.float32, device=x.device).to(BF16)
         S = Fl * Hl * Wl
         xcl = torch.empty((B, Fl, Hl, Wl, C), dtype=BF16, device=x.device)
-        check(_lib.load().ltxk_latent_denorm_cl(_p(x), _p(self.latents_mean), _p(self.latents_std), _p(xcl), B, C, S,
-                                                _stream()), "ltxk_latent_denorm_cl")
+        check(_lib.load().ltxk_latent_denorm_cl(_p(x), _p(nz) if tc else None, float(self.decode_noise_scale) if tc else 0.0,
+                                                _p(self.latents_mean), _p(self.latents_std), _p(xcl), B, C, S, _stream()),
+              "ltxk_latent_denorm_cl")
         x = conv3d(xcl, W["conv_in.conv.weight"], W["conv_in.conv.bias"], causal, PAD_REFLECT)
         for bi in range(7):
             pre = f"up_blocks.{bi}"

@@ -150,3 +150,24 @@ def test_denoise_graph_replay_is_bit_identical(dev, conditioned):
     graph = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig, use_graph=True, **kw)
     torch.cuda.synchronize()
     assert torch.equal(eager, graph)
+
+
+def test_x0_model(dev):
+    from mlx_video_amd.ltx_model import Modality, X0Model
+    cfg = _small_cfg()
+    W = O.make_weights(cfg, seed=15)
+    model = _model(cfg, dict(W), dev)
+    g = torch.Generator().manual_seed(46)
+    B, F, Hh, Ww, S = 1, 2, 4, 4, 64
+    N = F * Hh * Ww
+    lat = torch.randn(B, N, 128, generator=g).to(BF)
+    ctx = torch.randn(B, S, cfg.caption_channels, generator=g).to(BF)
+    ts = torch.full((B, N), 0.725).to(BF)
+    ts[:, :16] = 0.0
+    pos = torch.from_numpy(O.create_position_grid(B, F, Hh, Ww))
+    md = Modality(latent=lat.to(dev), timesteps=ts.to(dev), positions=pos.to(dev), context=ctx.to(dev))
+    v, _ = model(video=md)
+    x0, _ = X0Model(model)(video=md)
+    torch.cuda.synchronize()
+    ref = O.BF16.r(lat.float() - ts.float()[..., None] * v.float().cpu())          # utils.py:404-440 per-token sigma
+    assert torch.equal(x0.float().cpu(), ref)
