@@ -159,4 +159,16 @@ def test_denoise_fullsize_smoke(dev):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(a.float()).all())
     assert torch.equal(a, c)                      # deterministic
-    assert torch.equal(a, b)                      # batching the CFG pair does not change a single bit
+    # B=2 puts 128 of the 640 attention tiles in a short round whose workgroups split the keys (attention.hip):
+    # those rows sum in a different order than in the B=1 launches, so the pair is close, not identical ...
+    assert rel_l2(a, b) < 2e-3
+    # ... and with the split off, batching the CFG pair does not change a single bit
+    import os
+    os.environ["LTXK_FA_SPLIT"] = "0"
+    try:
+        a0 = denoise_dev(lat, pos, cp, cn, model, sig, cfg_scale=4.0, compile_step=True, cfg_batch=True)
+        b0 = denoise_dev(lat, pos, cp, cn, model, sig, cfg_scale=4.0, compile_step=True, cfg_batch=False)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["LTXK_FA_SPLIT"]
+    assert torch.equal(a0, b0)
