@@ -267,20 +267,28 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
       for (int j = 0; j < 16; ++j) o[db][j] = o[db][j] * a0 + xo[(db * 16 + j) * 64 + lane] * a1;
   }
 
-  // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+  // ---- epilogue: O[q][d] = O^T[d][q] / l, transposed through a wave-private 8 KiB LDS image so that every
+  // store instruction writes four whole 256-byte rows (16 B per lane) instead of 64 scattered 8-byte pieces
   const float inv = 1.0f / l_tot;
-  const int qout = q0 + r;
-  if (qout < p.Tq) {
-    bf16* op = p.out + ((size_t)b * p.Tq + qout) * p.ldo + h * FA_DH + 4 * hh;
+  if (KS == 1) __syncthreads();                       // every wave has left the K / V^T ring
+  char* stg = smem + (KS == 1 ? wave * 8192 : 2 * 17 * 1024 + (wave >> 1) * 8192);
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4v v;
+    for (int g = 0; g < 4; ++g) {
+      bf16x4v v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
-        *(bf16x4v*)(op + db * 32 + g * 8) = v;
-      }
+      for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
+      *(bf16x4v*)(stg + r * 256 + (((db * 4 + g) ^ (r & 15)) << 4) + hh * 8) = v;      // row q=r, d = 32db+8g+4hh..+3
+    }
+  {
+    bf16* ob = p.out + ((size_t)b * p.Tq) * p.ldo + h * FA_DH + (lane & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + (lane >> 4);
+      const bf16x8 v = *(const bf16x8*)(stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+      if (q0 + row < p.Tq) *(bf16x8*)(ob + (size_t)(q0 + row) * p.ldo) = v;
+    }
   }
 }
 
@@ -693,10 +701,10 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   LTXK_CHECK_ARG(q && k && vt && out, "ltxk_flash_attn_bf16: null pointer");
   LTXK_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0, "ltxk_flash_attn_bf16: bad dims");
   LTXK_CHECK_ARG(ldq >= H * FA_DH && ldk >= H * FA_DH && ldo >= H * FA_DH, "ltxk_flash_attn_bf16: row strides < H*128");
-  LTXK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "ltxk_flash_attn_bf16: row strides must be multiples of 8");
+  LTXK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "ltxk_flash_attn_bf16: row strides must be multiples of 8");
   const int tk_pad = (Tk + FA_BK - 1) / FA_BK * FA_BK;
   LTXK_CHECK_ARG(ldvt >= tk_pad && ldvt % 8 == 0, "ltxk_flash_attn_bf16: ldvt=%d must be >= %d (Tk rounded up to 64) and a multiple of 8", ldvt, tk_pad);
-  LTXK_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)out & 7) == 0, "ltxk_flash_attn_bf16: misaligned pointer");
+  LTXK_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)out & 15) == 0, "ltxk_flash_attn_bf16: misaligned pointer");
   FaParams p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.vt = (const bf16*)vt; p.out = (bf16*)out;
   p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;

@@ -12,9 +12,9 @@ What is injected instead of loaded (nothing exists offline and they are out of s
 #17/#21): text embeddings (the Gemma-3 text encoder's output tensor is an INPUT of this path), model
 weights (`weights=` dicts or ready modules; `model_repo` may point at a local directory of
 safetensors read by ``weights.py``), random draws (`noise_fn`: MLX's threefry stream is not
-reproducible, so seeds are not cross-compatible), audio (not supported).  mp4/ffmpeg writing is out
-of scope: frames are returned as the reference returns them (uint8 (F,H,W,3)) and `output_path`
-accepts `.npy`.
+reproducible, so seeds are not cross-compatible), audio (not supported).  Frames are returned as the reference returns them (uint8 (F,H,W,3));
+`output_path` accepts `.npy`, or a video file written through an ffmpeg child process when an ffmpeg binary
+is installed (media.write_video_ffmpeg); audio muxing is out of scope.
 """
 from __future__ import annotations
 
@@ -305,10 +305,12 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
     elapsed = time.perf_counter() - t_start
     if output_path:
         p = Path(output_path)
-        if p.suffix != ".npy":
-            raise ValueError("only .npy output is supported (mp4/ffmpeg writing is out of scope, SURVEY.md §2a #1)")
         p.parent.mkdir(parents=True, exist_ok=True)
-        np.save(p, video_np)
+        if p.suffix == ".npy":
+            np.save(p, video_np)
+        else:                                                          # generate.py:3900-3913 (ffmpeg encoder)
+            from .media import write_video_ffmpeg
+            write_video_ffmpeg(video_np, p, fps)
     if profile and verbose:
         print(timer.render(elapsed))
     if profile_json_path and timer.times_s:                          # generate.py:4158-4189 (same keys)

@@ -64,3 +64,36 @@ def frames_to_conditioning(frames: np.ndarray) -> torch.Tensor:
     keep = 1 + ((f - 1) // 8) * 8
     t = torch.from_numpy(np.ascontiguousarray(frames[:keep])).permute(3, 0, 1, 2)[None]
     return t * 2.0 - 1.0
+
+
+def ffmpeg_command(ffmpeg: str, width: int, height: int, fps: float, path: Union[str, Path], codec: str = "libx264",
+                   preset: str = "veryfast", crf: int = 18) -> list:
+    """Raw RGB24 frames on stdin -> yuv420p video file (the encoder settings of generate.py:1833-1877)."""
+    return [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}", "-r", str(fps), "-i", "-", "-an",
+            "-c:v", codec, "-preset", preset, "-crf", str(crf), "-pix_fmt", "yuv420p", str(path)]
+
+
+def write_video_ffmpeg(video_np: np.ndarray, path: Union[str, Path], fps: float, codec: str = "libx264",
+                       preset: str = "veryfast", crf: int = 18) -> None:
+    """(F,H,W,3) uint8 -> video file through an ffmpeg child process fed frame by frame (generate.py:1833-1893:
+    FileNotFoundError when ffmpeg is not installed, RuntimeError with ffmpeg's stderr when it fails).  There is no
+    OpenCV fallback here: callers that cannot encode write .npy frames instead."""
+    import shutil
+    import subprocess
+    if video_np.ndim != 4 or video_np.shape[-1] != 3 or video_np.dtype != np.uint8:
+        raise ValueError(f"expected (F,H,W,3) uint8 frames, got {video_np.shape} {video_np.dtype}")
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg is None:
+        raise FileNotFoundError("ffmpeg not found")
+    h, w = video_np.shape[1], video_np.shape[2]
+    proc = subprocess.Popen(ffmpeg_command(ffmpeg, w, h, fps, path, codec, preset, crf), stdin=subprocess.PIPE,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        for frame in video_np:
+            proc.stdin.write(np.ascontiguousarray(frame).tobytes())
+        proc.stdin.close()
+    except BrokenPipeError:
+        pass                                            # ffmpeg died early: its stderr says why
+    err = proc.stderr.read() if proc.stderr is not None else b""
+    if proc.wait() != 0:
+        raise RuntimeError(err.decode(errors="ignore"))

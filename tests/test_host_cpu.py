@@ -189,3 +189,32 @@ def test_media_and_checkpoint_keymaps(tmp_path):
     ew = weights.vae_encoder_weights(raw, "cpu")
     assert "down_blocks.0.res_blocks.1.conv1.weight" in ew and "per_channel_statistics.mean" in ew
     assert weights.sniff_timestep_conditioning(tmp_path / "m.safetensors") is True
+
+
+def test_ffmpeg_writer_contract(tmp_path, monkeypatch):
+    """generate.py:1833-1893: raw RGB24 pipe command; FileNotFoundError without ffmpeg; RuntimeError on failure."""
+    import shutil, stat
+    import numpy as np
+    from mlx_video_amd import media
+    cmd = media.ffmpeg_command("ffmpeg", 64, 32, 24.0, "o.mp4")
+    assert cmd[:12] == ["ffmpeg", "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", "64x32", "-r", "24.0", "-i", "-"]
+    assert cmd[-3:] == ["-pix_fmt", "yuv420p", "o.mp4"] and "libx264" in cmd and "18" in cmd
+    frames = np.zeros((3, 32, 64, 3), np.uint8)
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    with pytest.raises(FileNotFoundError):
+        media.write_video_ffmpeg(frames, tmp_path / "o.mp4", 24.0)
+    with pytest.raises(ValueError):
+        media.write_video_ffmpeg(frames.astype(np.float32), tmp_path / "o.mp4", 24.0)
+    # a stand-in encoder that counts stdin bytes proves frames are streamed whole and a failure surfaces stderr
+    fake = tmp_path / "ffmpeg"
+    fake.write_text("#!/bin/sh\nn=$(wc -c)\nfor a; do last=$a; done\necho $n > \"$last\"\n")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake))
+    media.write_video_ffmpeg(frames, tmp_path / "o.txt", 24.0)
+    assert int((tmp_path / "o.txt").read_text()) == frames.size
+    bad = tmp_path / "ffmpeg_bad"
+    bad.write_text("#!/bin/sh\ncat > /dev/null\necho boom >&2\nexit 3\n")
+    bad.chmod(bad.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(shutil, "which", lambda name: str(bad))
+    with pytest.raises(RuntimeError, match="boom"):
+        media.write_video_ffmpeg(frames, tmp_path / "o2.mp4", 24.0)
