@@ -2,7 +2,6 @@
 // 8- or 16-byte vectors; row reductions are wave64 shuffles (one wave per row); every bf16
 // rounding point of the reference's op chain is reproduced.
 #include "common.h"
-#include <stdlib.h>
 #include <math.h>
 
 namespace ltxk {
@@ -13,93 +12,71 @@ constexpr int MAX_CHUNKS = 16;     // D <= 16*512 = 8192
 // ---------------------------------------------------------------------------------------
 // rms_norm / layer_norm (no affine) + AdaLN modulation
 // ---------------------------------------------------------------------------------------
-// One wave per row.  A wave can also walk rows row0, row0+stride, ... with the next row's loads issued before the
-// current row is normalised and stored (LTXK_NORM_ROWS_PER_WAVE); at M=2560, D=4096 from cold operands that
-// measured 18.8 / 21.5 / 17.1 / 20.7 us for 1 / 2 / 3 / 4 rows per wave - no consistent gain over the plain
-// form, which stays the default.
+// One wave per row.  Tried and measured slower in the step (11.5-14 us -> 18.5 us per launch at M=2560): walking
+// several rows per wave with the next row's loads in flight, and requesting the modulation rows up front.
 template <bool LAYERNORM>
 __global__ __launch_bounds__(256) void norm_modulate_kernel(
     const bf16* __restrict__ x, bf16* __restrict__ y, int M, int D, float eps,
     const bf16* __restrict__ scale, const bf16* __restrict__ shift, int mod_stride,
-    const int32_t* __restrict__ mod_row, int stride) {
+    const int32_t* __restrict__ mod_row) {
   const int lane = threadIdx.x & 63;
-  int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-  if (row >= stride || row >= M) return;
+  const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const bf16* xr = x + (size_t)row * D;
   const int nch = D >> 9;  // chunks of 512 elements (64 lanes x 8)
-  bf16x8 v[MAX_CHUNKS], nx[MAX_CHUNKS];
+  bf16x8 v[MAX_CHUNKS];
+  float sum = 0.f, sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAX_CHUNKS; ++i)
-    if (i < nch) nx[i] = *(const bf16x8*)(x + (size_t)row * D + i * 512 + lane * 8);
-  for (; row < M; row += stride) {
+  for (int i = 0; i < MAX_CHUNKS; ++i) {
+    if (i < nch) {
+      v[i] = *(const bf16x8*)(xr + i * 512 + lane * 8);
 #pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) v[i] = nx[i];
-    const int nrow = row + stride;
-    if (nrow < M) {
-#pragma unroll
-      for (int i = 0; i < MAX_CHUNKS; ++i)
-        if (i < nch) nx[i] = *(const bf16x8*)(x + (size_t)nrow * D + i * 512 + lane * 8);
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[i][j];
+        sum += f;
+        sq += f * f;
+      }
     }
-    // the modulation rows depend only on the row index: request them now, under the x loads and the reduction
-    const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
-    bf16x8 scv[MAX_CHUNKS], shv[MAX_CHUNKS];
-    if (scale) {
+  }
+  float mean = 0.f, rstd;
+  if constexpr (LAYERNORM) {
+    mean = wave_sum(sum) / (float)D;
+    float var = 0.f;
 #pragma unroll
-      for (int i = 0; i < MAX_CHUNKS; ++i)
-        if (i < nch) {
-          scv[i] = *(const bf16x8*)(scale + mrow + i * 512 + lane * 8);
-          shv[i] = *(const bf16x8*)(shift + mrow + i * 512 + lane * 8);
-        }
-    }
-    float sum = 0.f, sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
+    for (int i = 0; i < MAX_CHUNKS; ++i)
       if (i < nch) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float f = (float)v[i][j];
-          sum += f;
-          sq += f * f;
+          const float d = (float)v[i][j] - mean;
+          var += d * d;
         }
       }
-    }
-    float mean = 0.f, rstd;
-    if constexpr (LAYERNORM) {
-      mean = wave_sum(sum) / (float)D;
-      float var = 0.f;
+    var = wave_sum(var) / (float)D;
+    rstd = rsqrtf(var + eps);
+  } else {
+    rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  }
+  const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
+  bf16* yr = y + (size_t)row * D;
 #pragma unroll
-      for (int i = 0; i < MAX_CHUNKS; ++i)
-        if (i < nch) {
+  for (int i = 0; i < MAX_CHUNKS; ++i) {
+    if (i < nch) {
+      const int col = i * 512 + lane * 8;
+      bf16x8 o;
+      if (scale) {
+        const bf16x8 sc = *(const bf16x8*)(scale + mrow + col);
+        const bf16x8 sh = *(const bf16x8*)(shift + mrow + col);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float d = (float)v[i][j] - mean;
-            var += d * d;
-          }
+        for (int j = 0; j < 8; ++j) {
+          const float n = rbf(((float)v[i][j] - mean) * rstd);
+          const float one_p = rbf(1.0f + (float)sc[j]);
+          o[j] = (bf16)(rbf(n * one_p) + (float)sh[j]);
         }
-      var = wave_sum(var) / (float)D;
-      rstd = rsqrtf(var + eps);
-    } else {
-      rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-    }
-    bf16* yr = y + (size_t)row * D;
+      } else {
 #pragma unroll
-    for (int i = 0; i < MAX_CHUNKS; ++i) {
-      if (i < nch) {
-        const int col = i * 512 + lane * 8;
-        bf16x8 o;
-        if (scale) {
-          const bf16x8 sc = scv[i], sh = shv[i];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float n = rbf(((float)v[i][j] - mean) * rstd);
-            const float one_p = rbf(1.0f + (float)sc[j]);
-            o[j] = (bf16)(rbf(n * one_p) + (float)sh[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)v[i][j] - mean) * rstd);
-        }
-        *(bf16x8*)(yr + col) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(((float)v[i][j] - mean) * rstd);
       }
+      *(bf16x8*)(yr + col) = o;
     }
   }
 }
@@ -327,16 +304,13 @@ static int norm_modulate_launch(bool ln, const void* x, void* y, int32_t M, int3
   LTXK_CHECK_ARG(D % 512 == 0 && D <= 512 * MAX_CHUNKS, "%s: D=%d must be a multiple of 512, <= %d", name, D, 512 * MAX_CHUNKS);
   LTXK_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift must both be set or both NULL", name);
   LTXK_CHECK_ARG(!scale || mod_stride % 8 == 0, "%s: mod_stride must be a multiple of 8", name);
-  static const int rpw = [] { const char* e = getenv("LTXK_NORM_ROWS_PER_WAVE"); return e ? atoi(e) : 1; }();
-  const int per = (M >= 1024 && rpw > 1) ? rpw : 1;       // rows per wave
-  const int stride = (M + per - 1) / per;                 // = number of waves that do work
-  const dim3 grid((stride + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
   if (ln)
     hipLaunchKernelGGL(norm_modulate_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, M, D, eps,
-                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row, stride);
+                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row);
   else
     hipLaunchKernelGGL(norm_modulate_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, M, D, eps,
-                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row, stride);
+                       (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row);
   LTXK_CHECK_LAUNCH(name);
   return LTXK_OK;
 }
