@@ -3,6 +3,7 @@
 // text_projection.py:22-25; ltx.py:130,455 — and the residual/gate algebra of
 // transformer.py:254,257,347 as epilogues.
 #include "gemm_core.h"
+#include <stdlib.h>
 
 #ifndef LTXK_STAGGER
 #define LTXK_STAGGER 0   // measured neutral (profiles/r01 notes); kept for A/B
@@ -24,6 +25,7 @@ struct GemmParams {
   int RT, CT;
   int T;  // tokens per batch for the transposed output
   float alpha;
+  int wide;  // 1: rows are written as whole 128-byte lines through an LDS image (needs ldo % 8 == 0, out 16-B aligned)
 };
 
 template <int TT, int EPI, bool TRANS>
@@ -79,6 +81,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     }
   };
 
+  // Residual epilogues: this tile's residual values are requested now (40 VGPRs at TT=5) and arrive under the
+  // main loop, instead of as a 21 MB read burst issued by every workgroup at once when the loop ends.  (The
+  // output may alias the residual: each element is read and written by this workgroup only.)
+  constexpr bool HAS_RES = !TRANS && (EPI == LTXK_EPI_BIAS_GATE_RES || EPI == LTXK_EPI_BIAS_RES || EPI == LTXK_EPI_SCALE_RES);
+  bf16x4 rres[HAS_RES ? TT : 1][4];
+  if constexpr (HAS_RES) {
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+      }
+    }
+  }
+
   f32x4 acc[TT][4];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
@@ -130,8 +152,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 
   // ---- epilogue ----
   if constexpr (!TRANS) {
-    // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j
+    // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j.  Written directly that is 16 rows x 32 bytes per store
+    // instruction; with p.wide each wave instead transposes its (16*TT x 64) block through a private LDS image
+    // (128-byte rows, 16-byte chunks XOR-swizzled by row) and stores 8 whole 128-byte lines per instruction.
     const int nq = (lane >> 4) * 4;
+    char* stg = smem + wave * (TT * 16 * 128);
+    if (p.wide) __syncthreads();                   // every wave has read its last fragments from the ring
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
@@ -159,22 +185,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
           for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
         } else if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) {
           const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)grow * p.gate_stride + n);
-          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+          const bf16x4 r = rres[tt][nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
         } else if constexpr (EPI == LTXK_EPI_BIAS_RES) {
-          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+          const bf16x4 r = rres[tt][nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
         } else if constexpr (EPI == LTXK_EPI_SCALE_RES) {
-          const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+          const bf16x4 r = rres[tt][nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(p.alpha * acc[tt][nt][j]);
         }
         bf16x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
-        *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+        if (p.wide) {
+          const int r = tt * 16 + (lane & 15), cg = lane >> 4;
+          *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
+        } else {
+          *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+        }
+      }
+    }
+    if (p.wide) {
+      const int c = lane & 7;
+      const int n = n0 + wn * 64 + c * 8;
+#pragma unroll
+      for (int i = 0; i < TT * 2; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int m = m0 + wm * TT * 16 + r;
+        const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        if (m < p.M && n < p.N) *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = v;
       }
     }
   } else {
@@ -298,6 +340,10 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.gate_row = a->gate_row;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldo = a->ldo; p.ldr = a->ldr;
   p.gate_stride = a->gate_stride; p.T = trans ? a->out_tokens_per_batch : 1; p.alpha = a->alpha;
+  static const int wide_env = [] { const char* e = getenv("LTXK_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  // not for the GELU epilogue: its direct stores already issue under the activation arithmetic, and staging
+  // them behind it measured 2 % slower on FF1
+  p.wide = (!trans && wide_env && a->epilogue != LTXK_EPI_BIAS_GELU && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0) ? 1 : 0;
   const int tt = pick_tt(a->M, a->N);
   const int bm = 32 * tt;
   p.RT = (a->M + bm - 1) / bm;
