@@ -125,6 +125,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     }
   };
 
+  // residual values of this tile: requested now, they arrive under the main loop (see gemm.hip)
+  constexpr bool HAS_RES = RES && !SPLIT;
+  bf16x4 rres[HAS_RES ? TT : 1][4];
+  if constexpr (HAS_RES) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
+        n = n < p.Cout ? n : p.Cout - 4;
+        rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.Cout + n);
+      }
+    }
+  }
+
   f32x4 acc[TT][4];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
@@ -169,8 +186,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   pipe.finish(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j
+  // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j.  bf16 outputs go through a wave-private LDS
+  // image (128-byte rows, chunks XOR-swizzled by row) and leave as whole 128-byte lines (see gemm.hip).
   const int nq = (lane >> 4) * 4;
+  const bool wide = !SPLIT && (p.Cout & 7) == 0;
+  char* stg = smem + wave * (TT * 16 * 128);
+  if (wide) __syncthreads();
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
@@ -187,15 +208,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
       float y[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
-      if constexpr (RES) {
-        const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.Cout + n);
+      if constexpr (HAS_RES) {
+        const bf16x4 r = rres[tt][nt];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = y[j] + (float)r[j];
       }
       bf16x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
-      *(bf16x4*)(p.out + (size_t)m * p.Cout + n) = o;
+      if (wide) {
+        const int r = tt * 16 + (lane & 15), cg = lane >> 4;
+        *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
+      } else {
+        *(bf16x4*)(p.out + (size_t)m * p.Cout + n) = o;
+      }
+    }
+  }
+  if (wide) {
+    const int c = lane & 7;
+    const int n = n0 + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < TT * 2; ++i) {
+      const int r = i * 8 + (lane >> 3);
+      const int m = m0 + wm * TT * 16 + r;
+      const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+      if (m < p.M && n < p.Cout) *(bf16x8*)(p.out + (size_t)m * p.Cout + n) = v;
     }
   }
 }
