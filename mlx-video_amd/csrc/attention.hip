@@ -78,12 +78,27 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
   const int b = bh / p.H, h = bh - b * p.H;
 
   // ---- Q fragments (B operand: lane (q=r, half hh) holds d = 16*ks + 8*hh + j) ----
-  int qrow = q0 + r;
-  qrow = qrow < p.Tq ? qrow : p.Tq - 1;
-  const bf16* qp = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + hh * 8;
+  // NW == 4: the wave's 32 x 256-byte Q block comes in as 8 LDS-DMA pieces of 4 whole rows (coalesced 256-byte
+  // segments) into a private 8 KiB corner of ring slot 1 - free until tile 1 is fetched, which happens only after
+  // the loop's first barrier - and the fragments are read from there; loading fragments straight from global
+  // touches 32 rows x 32 bytes per instruction.
   bf16x8 qf[8];
+  if (NW == 4) {
+    char* qreg = smem + FA_STAGE + wave * 8192;
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    for (int j = 0; j < 8; ++j) {
+      const int row = 4 * j + (lane >> 4);
+      int qrow = q0 + row;
+      qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+      glds16(p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + (((lane & 15) ^ (row & 15)) << 3), qreg + j * 1024);
+    }
+  } else {
+    int qrow = q0 + r;
+    qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+    const bf16* qp = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
 
   // ---- loader addressing ----
   // K piece = 4 keys x 256 B; lane i -> key row (i>>4), 16-B slot (i&15) holding chunk slot^(row&15)
@@ -124,6 +139,13 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
   const int nt = (p.Tk + FA_BK - 1) / FA_BK;
 #pragma unroll
   for (int i = 0; i < NPW; ++i) { issue_k(i, 0, 0); issue_v(i, 0, 0); }
+  if (NW == 4) {
+    // the Q pieces were issued first: they have landed once only the 2*NPW K/V pieces are outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    const char* qreg = smem + FA_STAGE + wave * 8192 + r * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qreg + (((ks * 2 + hh) ^ (r & 15)) << 4));
+  }
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const bool pre = t + 1 < nt;
