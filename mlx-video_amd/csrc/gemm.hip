@@ -291,11 +291,11 @@ static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t st
 
 // Row-tile height: minimise (rounds over 256 CUs) x (tile rows + fixed per-tile overhead).
 static int pick_tt(int M, int N) {
-  const int cand[4] = {5, 4, 2, 1};
+  const int cand[5] = {5, 4, 3, 2, 1};
   const int CT = (N + GEMM_BN - 1) / GEMM_BN;
   int best = 5;
   long best_cost = -1;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     const int bm = 32 * cand[i];
     const long RT = (M + bm - 1) / bm;
     const long rounds = (RT * CT + 255) / 256;
@@ -344,7 +344,8 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   // not for the GELU epilogue: its direct stores already issue under the activation arithmetic, and staging
   // them behind it measured 2 % slower on FF1
   p.wide = (!trans && wide_env && a->epilogue != LTXK_EPI_BIAS_GELU && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0) ? 1 : 0;
-  const int tt = pick_tt(a->M, a->N);
+  static const int tt_env = [] { const char* e = getenv("LTXK_GEMM_TT"); return e ? atoi(e) : 0; }();   // A/B runs only
+  const int tt = (tt_env >= 1 && tt_env <= 5) ? tt_env : pick_tt(a->M, a->N);
   const int bm = 32 * tt;
   p.RT = (a->M + bm - 1) / bm;
   p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
@@ -352,6 +353,7 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   switch (tt) {
     case 5: return dispatch_epi<5>(p, a->epilogue, trans, st);
     case 4: return dispatch_epi<4>(p, a->epilogue, trans, st);
+    case 3: return dispatch_epi<3>(p, a->epilogue, trans, st);
     case 2: return dispatch_epi<2>(p, a->epilogue, trans, st);
     default: return dispatch_epi<1>(p, a->epilogue, trans, st);
   }
