@@ -28,10 +28,6 @@ struct GemmParams {
   int wide;  // 1: rows are written as whole 128-byte lines through an LDS image (needs ldo % 8 == 0, out 16-B aligned)
 };
 
-// Persistent over tiles: workgroup b runs tiles b, b+grid, b+2*grid, ... (grid = CUs when there are more tiles than
-// CUs, i.e. FF1 / QK).  The LDS ring keeps rotating across tiles: the last two K-steps of a tile fetch K-steps 0
-// and 1 of the NEXT tile (where a single-tile kernel re-loads its last stage to keep the vmcnt count), so the
-// epilogue runs under that DMA and the next main loop starts on landed data instead of a cold ~2-3 us fill.
 template <int TT, int EPI, bool TRANS>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   using G = GemmGeom<TT, 4>;
@@ -41,272 +37,218 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int ntiles = p.RT * p.CT;
+
+  int rt, ct;
+  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
+  const int m0 = rt * G::BM, n0 = ct * GEMM_BN;
 
   // ---- loader: per-lane source pointers (row clamped, 16-byte chunk pre-swizzled) ----
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
+  const bf16* wptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int r = n0 + (wave * 4 + i) * 8 + lrow;
+    r = r < p.N ? r : p.N - 1;
+    wptr[i] = p.W + (size_t)r * p.K + chunk * 8;
+  }
   // Every wave issues exactly 4 W pieces + MAXA A pieces per stage, so one constant vmcnt retires a
   // stage.  A_PIECES is not a multiple of 8 (20 at BM=160): waves past A_REM own one piece fewer and
   // re-issue their last piece (same source, same LDS bytes: benign) to keep the count uniform.
   const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
   const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
-  int adst[G::MAXA], apiece[G::MAXA];
+  const bf16* aptr[G::MAXA];
+  int adst[G::MAXA];
 #pragma unroll
   for (int i = 0; i < G::MAXA; ++i) {
     const int pi = nA > 0 ? a0 + (i < nA ? i : nA - 1) : G::A_PIECES - 1;   // no own piece: re-issue the tile's last one
-    apiece[i] = pi;
+    int r = m0 + pi * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + chunk * 8;
     adst[i] = GEMM_W_STAGE_BYTES + (pi < G::A_PIECES ? pi : G::A_PIECES - 1) * 1024;
   }
   constexpr int PER_STAGE = 4 + G::MAXA;
   static_assert(PER_STAGE <= 7, "vmcnt immediates below assume <= 7 pieces per stage");
 
-  struct TilePtrs {
-    const bf16* w[4];
-    const bf16* a[G::MAXA];
-    int m0, n0;
-  };
-  auto setup = [&](int tile, TilePtrs& t) __attribute__((always_inline)) {
-    int rt, ct;
-    map_tile(tile, p.RT, p.CT, rt, ct);
-    t.m0 = rt * G::BM;
-    t.n0 = ct * GEMM_BN;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int r = t.n0 + (wave * 4 + i) * 8 + lrow;
-      r = r < p.N ? r : p.N - 1;
-      t.w[i] = p.W + (size_t)r * p.K + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < G::MAXA; ++i) {
-      int r = t.m0 + apiece[i] * 8 + lrow;
-      r = r < p.M ? r : p.M - 1;
-      t.a[i] = p.A + (size_t)r * p.lda + chunk * 8;
-    }
-  };
-
-  // i-th LDS-DMA piece of this wave for K-step kt of tile t into ring slot s (pieces 0..3 = W, 4.. = A)
-  auto issue_piece = [&](const TilePtrs& t, int i, int kt, int s) __attribute__((always_inline)) {
+  // i-th LDS-DMA piece of this wave for K-step kt into ring slot s (pieces 0..3 = W, 4.. = A)
+  auto issue_piece = [&](int i, int kt, int s) __attribute__((always_inline)) {
     char* base = smem + s * G::STAGE_BYTES;
     const int ko = kt * GEMM_BK;
     if (i < 4) {
-      glds16(t.w[i] + ko, base + (wave * 4 + i) * 1024);
+      glds16(wptr[i] + ko, base + (wave * 4 + i) * 1024);
     } else if (i < PER_STAGE) {
-      glds16(t.a[i - 4 < G::MAXA ? i - 4 : 0] + ko, base + adst[i - 4 < G::MAXA ? i - 4 : 0]);
+      glds16(aptr[i - 4 < G::MAXA ? i - 4 : 0] + ko, base + adst[i - 4 < G::MAXA ? i - 4 : 0]);
     }
   };
 
-  const int nk = p.K / GEMM_BK;
-  int tile = blockIdx.x;
-  TilePtrs cur, nxt;
-  setup(tile, cur);
+  // Residual epilogues: this tile's residual values are requested now (40 VGPRs at TT=5) and arrive under the
+  // main loop, instead of as a 21 MB read burst issued by every workgroup at once when the loop ends.  (The
+  // output may alias the residual: each element is read and written by this workgroup only.)
+  constexpr bool HAS_RES = !TRANS && (EPI == LTXK_EPI_BIAS_GATE_RES || EPI == LTXK_EPI_BIAS_RES || EPI == LTXK_EPI_SCALE_RES);
+  bf16x4 rres[HAS_RES ? TT : 1][4];
+  if constexpr (HAS_RES) {
+    const int nq = (lane >> 4) * 4;
 #pragma unroll
-  for (int i = 0; i < PER_STAGE; ++i) issue_piece(cur, i, 0, 0);
+    for (int tt = 0; tt < TT; ++tt) {
+      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
 #pragma unroll
-  for (int i = 0; i < PER_STAGE; ++i) issue_piece(cur, i, nk > 1 ? 1 : 0, 1);
-  int s = 0;
-
-  for (;;) {
-    const int m0 = cur.m0, n0 = cur.n0;
-    const int tile_next = tile + gridDim.x;
-    // the next tile's first two K-steps ride in this tile's last two (needs nk >= 2)
-    const bool pre_next = tile_next < ntiles && nk >= 2;
-    if (tile_next < ntiles) setup(tile_next, nxt);
-
-    // Residual epilogues: this tile's residual values are requested now (40 VGPRs at TT=5) and arrive under the
-    // main loop, instead of as a 21 MB read burst issued by every workgroup at once when the loop ends.  (The
-    // output may alias the residual: each element is read and written by this workgroup only.)
-    constexpr bool HAS_RES = !TRANS && (EPI == LTXK_EPI_BIAS_GATE_RES || EPI == LTXK_EPI_BIAS_RES || EPI == LTXK_EPI_SCALE_RES);
-    bf16x4 rres[HAS_RES ? TT : 1][4];
-    if constexpr (HAS_RES) {
-      const int nq = (lane >> 4) * 4;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
-        m = m < p.M ? m : p.M - 1;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          int n = n0 + wn * 64 + nt * 16 + nq;
-          n = n < p.N ? n : p.N - 4;
-          rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
-        }
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
       }
     }
+  }
 
-    f32x4 acc[TT][4];
+  f32x4 acc[TT][4];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
+  for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // piece source of K-step kt+2: this tile, or (tail) K-step kt+2-nk of the next tile, or (tail of the last tile)
-    // a harmless re-load of the last stage into a free slot - every K-step issues exactly PER_STAGE pieces
-    auto issue_ahead = [&](int i, int kt, int s2) __attribute__((always_inline)) {
-      const int kt2 = kt + 2;
-      if (kt2 < nk) issue_piece(cur, i, kt2, s2);
-      else if (pre_next) issue_piece(nxt, i, kt2 - nk, s2);
-      else issue_piece(cur, i, nk - 1, s2);
-    };
-    if constexpr (TT >= 2) {
-      auto kloop = [&](auto& pipe) __attribute__((always_inline)) {
-        pipe.init();
-        for (int kt = 0; kt < nk; ++kt) {
-          // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
-          wait_stage_and_barrier(PER_STAGE);
-          int s2 = s + 2;
-          s2 = s2 >= 3 ? s2 - 3 : s2;
-          pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_ahead(i, kt, s2); });
-          s = s + 1 == 3 ? 0 : s + 1;
-        }
-        pipe.finish(acc);
-      };
-#if LTXK_STAGGER
-      if (wave >= 4) {                  // SIMD partners of waves 0-3 run half a K-step out of phase
-        MmaPipe<TT, 4, TRANS, TT> pipe;
-        kloop(pipe);
-      } else
-#endif
-      {
-        MmaPipe<TT, 4, TRANS, 2> pipe;
-        kloop(pipe);
-      }
-    } else {
+  const int nk = p.K / GEMM_BK;
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
+  int s = 0;
+  if constexpr (TT >= 2) {
+    auto kloop = [&](auto& pipe) __attribute__((always_inline)) {
+      pipe.init();
       for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
         wait_stage_and_barrier(PER_STAGE);
         int s2 = s + 2;
         s2 = s2 >= 3 ? s2 - 3 : s2;
-        mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
-                                          [&](int i) { issue_ahead(i, kt, s2); });
+        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
+        pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
         s = s + 1 == 3 ? 0 : s + 1;
       }
+      pipe.finish(acc);
+    };
+#if LTXK_STAGGER
+    if (wave >= 4) {                  // SIMD partners of waves 0-3 run half a K-step out of phase
+      MmaPipe<TT, 4, TRANS, TT> pipe;
+      kloop(pipe);
+    } else
+#endif
+    {
+      MmaPipe<TT, 4, TRANS, 2> pipe;
+      kloop(pipe);
     }
-    // After the loop the ring slot read last (s_free) is idle; with pre_next the other two hold the next tile's
-    // K-steps 0 and 1 (possibly still landing).  Without it they hold dummy re-loads that must drain before the
-    // staging image below may reuse LDS.
-    const int s_free = s == 0 ? 2 : s - 1;
-    if (!pre_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_stage_and_barrier(PER_STAGE);
+      int s2 = s + 2;
+      s2 = s2 >= 3 ? s2 - 3 : s2;
+      const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
+      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
+                                        [&](int i) { issue_piece(i, kt2, s2); });
+      s = s + 1 == 3 ? 0 : s + 1;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue ----
-    if constexpr (!TRANS) {
-      // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j.  Written directly that is 16 rows x 32 bytes per
-      // store instruction; with p.wide each wave instead transposes its (16*TT x 64) block through a private LDS
-      // image (128-byte rows, 16-byte chunks XOR-swizzled by row), in two passes that together fit the idle ring
-      // slot, and stores 8 whole 128-byte lines per instruction.
-      const int nq = (lane >> 4) * 4;
-      constexpr int TA = (TT + 1) / 2;                      // row tiles in the first staging pass
-      char* stg = smem + s_free * G::STAGE_BYTES + wave * (TA * 16 * 128);
-      static_assert(8 * TA * 16 * 128 <= G::STAGE_BYTES, "staging pass exceeds one ring slot");
-      if (p.wide) __syncthreads();                          // every wave has read its last fragments from the ring
+  // ---- epilogue ----
+  if constexpr (!TRANS) {
+    // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j.  Written directly that is 16 rows x 32 bytes per store
+    // instruction; with p.wide each wave instead transposes its (16*TT x 64) block through a private LDS image
+    // (128-byte rows, 16-byte chunks XOR-swizzled by row) and stores 8 whole 128-byte lines per instruction.
+    const int nq = (lane >> 4) * 4;
+    char* stg = smem + wave * (TT * 16 * 128);
+    if (p.wide) __syncthreads();                   // every wave has read its last fragments from the ring
 #pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        const int tt0 = pass == 0 ? 0 : TA, tt1 = pass == 0 ? TA : TT;
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-          if (tt < tt0 || tt >= tt1) continue;
-          const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
-          if (m >= p.M) continue;
-          int grow = 0;
-          if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) grow = p.gate_row ? p.gate_row[m] : 0;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + nq;
-            if (n >= p.N) continue;
-            float y[4];
-            if (p.bias) {
-              const bf16x4 b = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j]);
-            }
-            if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
-            } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
-            } else if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) {
-              const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)grow * p.gate_stride + n);
-              const bf16x4 r = rres[tt][nt];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
-            } else if constexpr (EPI == LTXK_EPI_BIAS_RES) {
-              const bf16x4 r = rres[tt][nt];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
-            } else if constexpr (EPI == LTXK_EPI_SCALE_RES) {
-              const bf16x4 r = rres[tt][nt];
-#pragma unroll
-              for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(p.alpha * acc[tt][nt][j]);
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
-            if (p.wide) {
-              const int r = (tt - tt0) * 16 + (lane & 15), cg = lane >> 4;
-              *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
-            } else {
-              *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
-            }
-          }
-        }
-        if (p.wide) {
-          const int c = lane & 7;
-          const int n = n0 + wn * 64 + c * 8;
-#pragma unroll
-          for (int i = 0; i < TA * 2; ++i) {
-            const int r = i * 8 + (lane >> 3);
-            if (r >= (tt1 - tt0) * 16) continue;
-            const int m = m0 + wm * TT * 16 + tt0 * 16 + r;
-            const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
-            if (m < p.M && n < p.N) *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = v;
-          }
-        }
-      }
-    } else {
-      // acc[tt][nt][j]: n = lane&15, token = 4*(lane>>4) + j ; out[(b*N + n)*ldo + t]
-      const int tq = (lane >> 4) * 4;
+    for (int tt = 0; tt < TT; ++tt) {
+      const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      int grow = 0;
+      if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) grow = p.gate_row ? p.gate_row[m] : 0;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+        const int n = n0 + wn * 64 + nt * 16 + nq;
         if (n >= p.N) continue;
-        const float b = p.bias ? (float)p.bias[n] : 0.f;
+        float y[4];
+        if (p.bias) {
+          const bf16x4 b = *(const bf16x4*)(p.bias + n);
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-          const int m = m0 + wm * TT * 16 + tt * 16 + tq;
-          if (m >= p.M) continue;
-          bf16x4 o;
+          for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
+        } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[tt][nt][j] + b);
-          const int bidx = m / p.T, t = m - bidx * p.T;
-          bf16* dst = p.out + ((size_t)bidx * p.N + n) * p.ldo + t;
-          if ((p.T & 3) == 0 && m + 3 < p.M) {
-            *(bf16x4*)dst = o;
-          } else {
+          for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j]);
+        }
+        if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int mj = m + j;
-              if (mj < p.M) {
-                const int bj = mj / p.T, tj = mj - bj * p.T;
-                p.out[((size_t)bj * p.N + n) * p.ldo + tj] = o[j];
-              }
+          for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) {
+          const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)grow * p.gate_stride + n);
+          const bf16x4 r = rres[tt][nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_RES) {
+          const bf16x4 r = rres[tt][nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
+        } else if constexpr (EPI == LTXK_EPI_SCALE_RES) {
+          const bf16x4 r = rres[tt][nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(p.alpha * acc[tt][nt][j]);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+        if (p.wide) {
+          const int r = tt * 16 + (lane & 15), cg = lane >> 4;
+          *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
+        } else {
+          *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+        }
+      }
+    }
+    if (p.wide) {
+      const int c = lane & 7;
+      const int n = n0 + wn * 64 + c * 8;
+#pragma unroll
+      for (int i = 0; i < TT * 2; ++i) {
+        const int r = i * 8 + (lane >> 3);
+        const int m = m0 + wm * TT * 16 + r;
+        const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        if (m < p.M && n < p.N) *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = v;
+      }
+    }
+  } else {
+    // acc[tt][nt][j]: n = lane&15, token = 4*(lane>>4) + j ; out[(b*N + n)*ldo + t]
+    const int tq = (lane >> 4) * 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+      if (n >= p.N) continue;
+      const float b = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int m = m0 + wm * TT * 16 + tt * 16 + tq;
+        if (m >= p.M) continue;
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[tt][nt][j] + b);
+        const int bidx = m / p.T, t = m - bidx * p.T;
+        bf16* dst = p.out + ((size_t)bidx * p.N + n) * p.ldo + t;
+        if ((p.T & 3) == 0 && m + 3 < p.M) {
+          *(bf16x4*)dst = o;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int mj = m + j;
+            if (mj < p.M) {
+              const int bj = mj / p.T, tj = mj - bj * p.T;
+              p.out[((size_t)bj * p.N + n) * p.ldo + tj] = o[j];
             }
           }
         }
       }
-    }
-
-    if (tile_next >= ntiles) break;
-    tile = tile_next;
-    cur = nxt;
-    if (!pre_next) {     // nk == 1: no tail to ride in; cold prologue for the next tile (the drain above already ran)
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < PER_STAGE; ++i) issue_piece(cur, i, 0, 0);
-#pragma unroll
-      for (int i = 0; i < PER_STAGE; ++i) issue_piece(cur, i, 0, 1);
-      s = 0;
     }
   }
 }
@@ -327,17 +269,7 @@ static int launch(const GemmParams& p, hipStream_t stream) {
     }
     attr_dev = dev;
   }
-  static thread_local int cus = 0;
-  if (dev != attr_dev || cus == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus = n;
-  }
-  static const int persist = [] { const char* e = getenv("LTXK_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  const int tiles = p.RT * p.CT;
-  // one workgroup per CU (156 KB of LDS each); more tiles than CUs: each workgroup walks tiles b, b+CUs, ...
-  const int grid = (persist && tiles > cus && tiles % cus == 0) ? cus : tiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
   LTXK_CHECK_LAUNCH("ltxk_gemm_bf16");
   return LTXK_OK;
 }
