@@ -1,6 +1,7 @@
 """Runs the single-GPU configurations of BASELINE.json end to end with synthetic (random-init) weights and
 random text embeddings, through generate_video, and prints one JSON line per config with the phase times.
-Config 4 (8 GPUs) is the driver's scaling run of bench.py."""
+Config 4 (512x512x97, 4 seeds over 8 GPUs) runs here as ONE seed on one GPU: same per-GPU work and the temporal-tiled
+VAE decode; the multi-GPU form is the driver's scaling run of bench.py."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -46,6 +47,7 @@ enc = VideoEncoder(enc_weights())
 runs = [
     ("config1 dev 128x128x9 1 step", dict(pipeline=PipelineType.DEV, height=128, width=128, num_frames=9, num_inference_steps=1)),
     ("config2 dev 512x512x33 40 steps CFG4", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=33, num_inference_steps=40)),
+    ("config4 (one seed) dev 512x512x97 40 steps CFG4, temporal-tiled decode", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=97, num_inference_steps=40, tiling="temporal")),
     ("config3 distilled 768x768x65 two-stage", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3)),
     ("config5 ic_lora 768x768x65 video-cond", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
                                                  video_conditionings=[((torch.rand((1, 3, 65, 768, 768), generator=g, device=dev) * 2 - 1).to(BF), 0, 1.0)])),
