@@ -82,7 +82,7 @@ int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
  * q, k, vt, out 16-byte aligned; ldq, ldk, ldo multiples of 8.  Environment switches for A/B runs (read by the
  * library, never required): LTXK_FA_SPLIT=0 disables the key-split of the short last round of workgroups
  * (results then do not depend on how many (batch, head) pairs share a launch), LTXK_FA_XCD=0 the XCD-local
- * tile order, LTXK_FA_VARIANT={4,5,8,2} selects a kernel form.
+ * tile order, LTXK_FA_VARIANT={4,5,8} selects a kernel form.
  * ------------------------------------------------------------------------------------- */
 int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
                          const void* vt, int32_t ldvt, void* out, int32_t ldo,

@@ -341,176 +341,6 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
 
 
 // ---------------------------------------------------------------------------------------
-// 48-KiB variant: K tiles double-buffered (2 x 16 KiB), the V^T tile single-buffered (16 KiB) and
-// re-filled right after the workgroup has finished P.V of the previous tile, so its DMA flies under
-// this tile's QK^T + softmax.  Three workgroups (12 waves) fit a CU instead of two: at Tq=1280 and
-// B*H=64 the 640 workgroups then run in one wave of 768 slots instead of 1.25 rounds of 512, and the
-// third wave per SIMD gives the scheduler more to overlap softmax VALU with another wave's MFMAs.
-// ---------------------------------------------------------------------------------------
-constexpr int FA2_LDS = 2 * FA_K_BYTES + FA_V_BYTES;
-
-__global__ __launch_bounds__(256, 3) void flash_attn_kernel_v2(FaParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = 4;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  int bh, qt;
-  fa_map(p, blockIdx.x, bh, qt);
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = qt * (FA_QW * NW) + wave * FA_QW;
-
-  int qrow = q0 + r;
-  qrow = qrow < p.Tq ? qrow : p.Tq - 1;
-  const bf16* qp = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + hh * 8;
-  bf16x8 qf[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-
-  const int k_lrow = lane >> 4, k_slot = lane & 15;
-  const int v_lrow = lane >> 3, v_slot = lane & 7;
-  const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
-  const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
-  char* const sv = smem + 2 * FA_K_BYTES;
-
-  auto issue_k = [&](int t) __attribute__((always_inline)) {   // 4 pieces per wave
-    char* sk = smem + (t & 1) * FA_K_BYTES;
-    const int key0 = t * FA_BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave * 4 + i;
-      const int row = piece * 4 + k_lrow;
-      int key = key0 + row;
-      key = key < p.Tk ? key : p.Tk - 1;
-      fa_glds16(kbase + (size_t)key * p.ldk + (k_slot ^ (row & 15)) * 8, sk + piece * 1024);
-    }
-  };
-  auto issue_v = [&](int t) __attribute__((always_inline)) {   // 4 pieces per wave
-    const int key0 = t * FA_BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = wave * 4 + i;
-      const int d = piece * 8 + v_lrow;
-      fa_glds16(vbase + (size_t)d * p.ldvt + key0 + (v_slot ^ ((d >> 1) & 7)) * 8, sv + piece * 1024);
-    }
-  };
-
-  f32x16 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-
-  const int nt = (p.Tk + FA_BK - 1) / FA_BK;
-  issue_k(0);
-  for (int t = 0; t < nt; ++t) {
-    // (A) everyone is done with P.V(t-1): V buffer and K buffer (t+1)&1 are free; K(t) has landed
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    issue_v(t);
-    if (t + 1 < nt) issue_k(t + 1);
-    const char* sk = smem + (t & 1) * FA_K_BYTES;
-
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s[kb][j] = 0.f;
-      const int row = kb * 32 + r;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const int chunk = ks * 2 + hh;
-        const bf16x8 kf = *(const bf16x8*)(sk + row * 256 + ((chunk ^ (row & 15)) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-      }
-    }
-    if (t == nt - 1 && (p.Tk & (FA_BK - 1)) != 0) {
-      const int kbase_i = t * FA_BK + 4 * hh;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int key = kbase_i + kb * 32 + (j & 3) + 8 * (j >> 2);
-          if (key >= p.Tk) s[kb][j] = -1e30f;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kb][j]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // Deferred rescale: the running max is only raised (and O, l rescaled: 65 VALU ops per lane) when some
-    // row's max grew by more than 2^FA_DEFER in the exponent domain; otherwise P is taken against the old
-    // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
-    // tile's P is exponentiated after the decision and the previous tile's P.V is complete, so everything
-    // scaled against the old max is rescaled exactly once.
-    if (__any((mx - m_run) * p.c > FA_DEFER)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
-    }
-    const float mc = m_run * p.c;
-    float psum = 0.f;
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][j], p.c, -mc));
-        psum += e;
-        pb[kb][j >> 3][j & 7] = (bf16)e;
-      }
-    l_run += psum;
-
-    // (B) V(t) has landed in every wave's share (the K(t+1) pieces, issued after it, may still fly)
-    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      const int d = db * 32 + r;
-      const char* vrow = sv + d * 128 + hh * 8;
-      const int sw = (d >> 1) & 7;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-          const int c0 = kb * 4 + 2 * sidx;
-          const bf16x4v lo = *(const bf16x4v*)(vrow + ((c0 ^ sw) << 4));
-          const bf16x4v hi = *(const bf16x4v*)(vrow + (((c0 + 1) ^ sw) << 4));
-          bf16x8 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-          vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][sidx], o[db], 0, 0, 0);
-        }
-    }
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int qout = q0 + r;
-  if (qout < p.Tq) {
-    bf16* op = p.out + ((size_t)b * p.Tq + qout) * p.ldo + h * FA_DH + 4 * hh;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4v v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
-        *(bf16x4v*)(op + db * 32 + g * 8) = v;
-      }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------
 // Ping-pong form: one workgroup of 8 waves (256 query rows) per CU, K / V^T tiles in a 4-deep LDS ring
 // (128 KiB, tiles fetched three ahead).  Per tile a wave has a VALU phase X (online softmax of S(t): ~1000
 // cycles, half of it quarter-rate v_exp) and an MFMA phase Y (O += P(t).V(t), then S(t+1) = K(t+1).Q^T:
@@ -744,11 +574,11 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   // Variants measured at B=2,H=32 (scripts/prof_attn.py; Tq=Tk=1280 / Tq=Tk=5184): 4-wave/64 KiB with the
   // tail split (default) 630 / 945 TF/s; without the split 600 / 920; 8-wave ping-pong (variant 8) 565 / 930;
   // 5-wave/160-row form (one exact round at 1280, but 10 waves per CU load the SIMDs 3,3,2,2) 554 / 580;
-  // 48-KiB/3-workgroup form (v2: register-capped at 168, spills) ~430.  Ablating the ping-pong kernel at
+  // a 48-KiB/3-workgroup form (register-capped at 168, spilled) ~430, removed.  Ablating the ping-pong kernel at
   // Tq=Tk=5184 (982 us): no softmax 838, no DMA 858, neither 761, MFMAs + barriers only 636 us - i.e. the
   // MFMA stream alone already runs at a DVFS-lowered ~1.5-1.6 GHz, and LDS reads, DMA and softmax each add
   // 10-15 % on top; none of them alone is the bound.
-  // LTXK_FA_VARIANT={4,5,8,2}, LTXK_FA_XCD={1,0}, LTXK_FA_SPLIT={1,0} select forms for A/B runs.
+  // LTXK_FA_VARIANT={4,5,8}, LTXK_FA_XCD={1,0}, LTXK_FA_SPLIT={1,0} select forms for A/B runs.
   static const int variant = [] { const char* e = getenv("LTXK_FA_VARIANT"); return e ? atoi(e) : 4; }();
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
   const int rows = variant == 5 ? 160 : variant == 8 ? PP_BQ : 128;
@@ -780,14 +610,6 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
       attr8_dev = dev;
     }
     hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, (hipStream_t)stream, p);
-  } else if (variant == 2) {
-    static thread_local int attr2_dev = -1;
-    if (dev != attr2_dev) {
-      hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel_v2, hipFuncAttributeMaxDynamicSharedMemorySize, FA2_LDS);
-      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
-      attr2_dev = dev;
-    }
-    hipLaunchKernelGGL(flash_attn_kernel_v2, grid, dim3(256), FA2_LDS, (hipStream_t)stream, p);
   } else if (variant == 5) {
     hipLaunchKernelGGL(flash_attn_kernel<5>, grid, dim3(320), FA_LDS, (hipStream_t)stream, p);
   } else {
