@@ -543,288 +543,6 @@ __global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(FaParams p) {
   }
 }
 
-
-// ---------------------------------------------------------------------------------------
-// 64 query rows per wave, one wave per SIMD (the whole 512-entry register file), one 4-wave workgroup per CU:
-// 256 rows share each K / V^T tile (half the L2->LDS traffic of the 128-row forms) in a 4-deep 128 KiB ring.
-// A wave owns two 32-row blocks A and B and alternates them so that every MFMA phase runs beside softmax
-// arithmetic of the OTHER block, placed piece by piece after the MFMAs in program order:
-//   P1: S_A = K(t).Q_A^T        16 MFMAs | exp / row-sum / pack of S_B(t-1) -> P_B        (7 VALU per MFMA)
-//   P2: O_B += V^T(t-1).P_B     16 MFMAs | running row max of S_A(t), then the rescale decision for A
-//   P3: S_B = K(t).Q_B^T        16 MFMAs | exp / row-sum / pack of S_A(t) -> P_A
-//   P4: O_A += V^T(t).P_A       16 MFMAs | running row max of S_B(t), then the rescale decision for B
-// so no S buffer is ever needed twice and the matrix pipe never waits for a softmax of its own block.
-// Tile u lives in ring slot u&3; tile t+2 is fetched during iteration t (slot (t-2)&3: V^T(t-1) in slot (t-1)&3
-// is still needed by P2); one barrier per tile.
-// ---------------------------------------------------------------------------------------
-constexpr int W64_NS = 4;
-constexpr int W64_LDS = W64_NS * FA_STAGE;
-constexpr int W64_BQ = 256;
-#define FA_SB() __builtin_amdgcn_sched_barrier(0)
-struct FaYes { static constexpr bool value = true; };
-struct FaNo { static constexpr bool value = false; };
-
-__global__ __launch_bounds__(256, 1) void flash_attn_w64_kernel(FaParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  int bh, qt;
-  fa_map(p, blockIdx.x, bh, qt);
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = qt * W64_BQ + wave * 64;
-  const int nt = (p.Tk + FA_BK - 1) / FA_BK;
-
-  // ---- Q: the wave's 64 x 256-byte block by LDS-DMA into its 16 KiB corner of ring slots 2-3 ----
-  {
-    char* qreg = smem + 2 * FA_STAGE + wave * 16384;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = 4 * j + (lane >> 4);
-      int qrow = q0 + row;
-      qrow = qrow < p.Tq ? qrow : p.Tq - 1;
-      glds16(p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + (((lane & 15) ^ (row & 15)) << 3), qreg + j * 1024);
-    }
-  }
-  const int k_lrow = lane >> 4, k_slot = lane & 15;
-  const int v_lrow = lane >> 3, v_slot = lane & 7;
-  const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
-  const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
-  // piece j (0..3: K, 4..7: V^T) of this wave for tile t -> ring slot t&3; past the end: harmless re-load of the last tile
-  auto issue = [&](int j, int t) __attribute__((always_inline)) {
-    char* st = smem + (t & 3) * FA_STAGE;
-    t = t < nt ? t : nt - 1;
-    const int piece = wave + 4 * (j & 3);
-    if (j < 4) {
-      const int row = piece * 4 + k_lrow;
-      int key = t * FA_BK + row;
-      key = key < p.Tk ? key : p.Tk - 1;
-      glds16(kbase + (size_t)key * p.ldk + (k_slot ^ (row & 15)) * 8, st + piece * 1024);
-    } else {
-      const int d = piece * 8 + v_lrow;
-      glds16(vbase + (size_t)d * p.ldvt + t * FA_BK + (v_slot ^ ((d >> 1) & 7)) * 8, st + FA_K_BYTES + piece * 1024);
-    }
-  };
-#pragma unroll
-  for (int j = 0; j < 8; ++j) issue(j, 0);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) issue(j, 1);
-
-  // rolling fragment registers (see fa_body_swp): fr[i] is re-requested right after the MFMA that read it
-  bf16x8 fr[4];
-  const int krow = fa_pi(r) * 256, khx = hh ^ (fa_pi(r) & 15);
-  auto ld_k = [&](int t, int g, int i) __attribute__((always_inline)) {
-    const char* sk = smem + (t & 3) * FA_STAGE + (g >> 1) * 8192 + krow;
-    return *(const bf16x8*)(sk + (((((g & 1) * 4 + i) * 2) ^ khx) << 4));
-  };
-  const int vrow0 = r * 128, vsw = (r >> 1) & 7;
-  auto ld_v = [&](int t, int db, int i) __attribute__((always_inline)) {
-    const char* sv = smem + (t & 3) * FA_STAGE + FA_K_BYTES + db * 4096 + vrow0;
-    return *(const bf16x8*)(sv + ((((i >> 1) * 4 + 2 * (i & 1) + hh) ^ vsw) << 4));
-  };
-
-  f32x16 oA[4], oB[4], sA[2], sB[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { oA[i][j] = 0.f; oB[i][j] = 0.f; }
-  float mA = -1e30f, lA = 0.f, mB = -1e30f, lB = 0.f;
-  bf16x8 pA[2][2], pB[2][2];
-
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the 16 Q pieces were issued first
-  bf16x8 qfA[8], qfB[8];
-  {
-    const char* qreg = smem + 2 * FA_STAGE + wave * 16384 + r * 256;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      qfA[ks] = *(const bf16x8*)(qreg + (((ks * 2 + hh) ^ (r & 15)) << 4));
-      qfB[ks] = *(const bf16x8*)(qreg + 32 * 256 + (((ks * 2 + hh) ^ (r & 15)) << 4));
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tile 0 visible; every Q corner has been read
-
-  // ---- phase bodies ----
-  // S = K(t) . Q^T with a piece of `filler(idx)` after every MFMA; `nextfr(i)` prefetches the next phase's first fragments
-  auto qk_phase = [&](f32x16 (&S)[2], const bf16x8 (&qf)[8], int t, auto&& filler, auto&& nextfr, int dma0, int tdma)
-                      __attribute__((always_inline)) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) S[kb][j] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g == 0) issue(dma0, tdma);
-      if (g == 2) issue(dma0 + 1, tdma);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        S[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], qf[(g & 1) * 4 + i], S[g >> 1], 0, 0, 0);
-        if (g + 1 < 4) fr[i] = ld_k(t, g + 1, i);
-        else nextfr(i);
-        FA_SB();
-        filler(g * 4 + i);
-        FA_SB();
-      }
-    }
-  };
-  // O^T += V^T(t) . P^T with a piece of `filler(idx)` after every MFMA
-  auto pv_phase = [&](f32x16 (&o)[4], const bf16x8 (&pb)[2][2], int t, auto&& filler, auto&& nextfr, int dma0, int tdma)
-                      __attribute__((always_inline)) {
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      if (db == 0) issue(dma0, tdma);
-      if (db == 2) issue(dma0 + 1, tdma);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pb[i >> 1][i & 1], o[db], 0, 0, 0);
-        if (db + 1 < 4) fr[i] = ld_v(t, db + 1, i);
-        else nextfr(i);
-        FA_SB();
-        filler(db * 4 + i);
-        FA_SB();
-      }
-    }
-  };
-  // filler pieces
-  auto exp_piece = [&](const f32x16 (&S)[2], bf16x8 (&pb)[2][2], float mc, float& psum, int idx) __attribute__((always_inline)) {
-    const int e0 = idx * 2, kb = e0 >> 4, j = e0 & 15;
-    const float x0 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][j], p.c, -mc));
-    const float x1 = __builtin_amdgcn_exp2f(__builtin_fmaf(S[kb][j + 1], p.c, -mc));
-    psum += x0;
-    psum += x1;
-    pb[kb][j >> 3][j & 7] = (bf16)x0;
-    pb[kb][j >> 3][(j & 7) + 1] = (bf16)x1;
-  };
-  auto max_piece = [&](const f32x16 (&S)[2], float& mx, int idx) __attribute__((always_inline)) {
-    const int e0 = idx * 2;
-    mx = fmaxf(mx, fmaxf(S[e0 >> 4][e0 & 15], S[e0 >> 4][(e0 & 15) + 1]));
-  };
-  auto decide = [&](float mx, float& m_run, float& l_run, f32x16 (&o)[4]) __attribute__((always_inline)) {
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (__any((mx - m_run) * p.c > FA_DEFER)) {          // deferred rescale, see fa_body
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
-    }
-  };
-  auto mask_tail = [&](f32x16 (&S)[2], int t) __attribute__((always_inline)) {
-    if (t == nt - 1 && (p.Tk & (FA_BK - 1)) != 0) {
-      const int kbase_i = t * FA_BK + 8 * hh;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (kbase_i + kb * 32 + fa_acc_key(j) >= p.Tk) S[kb][j] = -1e30f;
-    }
-  };
-
-  // one tile.  FIRST: no tile t-1 yet (P1 has no softmax filler, P2 is skipped).  LASTCHK: the tile may be the ragged last one.
-  auto tile = [&](auto first, auto lastchk, int t) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first)::value, LASTCHK = decltype(lastchk)::value;
-    // P1
-    {
-      const float mc = mB * p.c;
-      float psum = 0.f;
-      qk_phase(sA, qfA, t,
-               [&](int idx) __attribute__((always_inline)) { if (!FIRST) exp_piece(sB, pB, mc, psum, idx); },
-               [&](int i) __attribute__((always_inline)) { fr[i] = FIRST ? ld_k(t, 0, i) : ld_v(t - 1, 0, i); }, 0, t + 2);
-      lB += psum;
-    }
-    if (LASTCHK) mask_tail(sA, t);
-    // P2
-    {
-      float mx = sA[0][0];
-      if (!FIRST) {
-        pv_phase(oB, pB, t - 1, [&](int idx) __attribute__((always_inline)) { max_piece(sA, mx, idx); },
-                 [&](int i) __attribute__((always_inline)) { fr[i] = ld_k(t, 0, i); }, 2, t + 2);
-      } else {
-#pragma unroll
-        for (int idx = 0; idx < 16; ++idx) max_piece(sA, mx, idx);
-        issue(2, t + 2);
-        issue(3, t + 2);
-      }
-      decide(mx, mA, lA, oA);
-    }
-    // P3
-    {
-      const float mc = mA * p.c;
-      float psum = 0.f;
-      qk_phase(sB, qfB, t, [&](int idx) __attribute__((always_inline)) { exp_piece(sA, pA, mc, psum, idx); },
-               [&](int i) __attribute__((always_inline)) { fr[i] = ld_v(t, 0, i); }, 4, t + 2);
-      lA += psum;
-    }
-    if (LASTCHK) mask_tail(sB, t);
-    // P4
-    {
-      float mx = sB[0][0];
-      pv_phase(oA, pA, t, [&](int idx) __attribute__((always_inline)) { max_piece(sB, mx, idx); },
-               [&](int i) __attribute__((always_inline)) { (void)i; }, 6, t + 2);
-      decide(mx, mB, lB, oB);
-    }
-    // tile t+1 has landed (the 8 pieces of tile t+2 may still fly) and becomes visible; every wave is done with tile t
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fr[i] = ld_k(t + 1, 0, i);             // first fragments of the next tile's P1
-  };
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fr[i] = ld_k(0, 0, i);
-  tile(FaYes{}, FaYes{}, 0);
-  int t = 1;
-  for (; t + 1 < nt; ++t) tile(FaNo{}, FaNo{}, t);
-  if (t < nt) tile(FaNo{}, FaYes{}, t);
-  // drain: softmax and P.V of block B for the last tile
-  {
-    const int tl = nt - 1;
-    const float mc = mB * p.c;
-    float psum = 0.f;
-#pragma unroll
-    for (int idx = 0; idx < 16; ++idx) exp_piece(sB, pB, mc, psum, idx);
-    lB += psum;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fr[i] = ld_v(tl, 0, i);
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        oB[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i], pB[i >> 1][i & 1], oB[db], 0, 0, 0);
-        if (db + 1 < 4) fr[i] = ld_v(tl, db + 1, i);
-      }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                       // every wave has left the ring
-
-  // ---- epilogue: each 32-row block transposed through a wave-private 8 KiB LDS image (see fa_body) ----
-  auto store_block = [&](f32x16 (&o)[4], float l_run, int qb) __attribute__((always_inline)) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    char* stg = smem + wave * 16384 + (qb - q0 >= 32 ? 8192 : 0);
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4v v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
-        *(bf16x4v*)(stg + r * 256 + (((db * 4 + g) ^ (r & 15)) << 4) + hh * 8) = v;
-      }
-    bf16* ob = p.out + ((size_t)b * p.Tq) * p.ldo + h * FA_DH + (lane & 15) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = i * 4 + (lane >> 4);
-      const bf16x8 v = *(const bf16x8*)(stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
-      if (qb + row < p.Tq) *(bf16x8*)(ob + (size_t)(qb + row) * p.ldo) = v;
-    }
-  };
-  store_block(oA, lA, q0);
-  store_block(oB, lB, q0 + 32);
-}
-
 }  // namespace ltxk
 
 extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
@@ -863,7 +581,7 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   // LTXK_FA_VARIANT={4,5,8}, LTXK_FA_XCD={1,0}, LTXK_FA_SPLIT={1,0} select forms for A/B runs.
   static const int variant = [] { const char* e = getenv("LTXK_FA_VARIANT"); return e ? atoi(e) : 4; }();
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
-  const int rows = variant == 5 ? 160 : (variant == 8 || variant == 7) ? 256 : 128;
+  const int rows = variant == 5 ? 160 : variant == 8 ? PP_BQ : 128;
   p.QT = (Tq + rows - 1) / rows;
   p.xcd = (xcd_map && (B * H) % 8 == 0) ? 1 : 0;
   // read per call (not cached) so one process can A/B it: with the split on, a tile in the short round sums its
@@ -892,14 +610,6 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
       attr8_dev = dev;
     }
     hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, (hipStream_t)stream, p);
-  } else if (variant == 7) {
-    static thread_local int attr7_dev = -1;
-    if (dev != attr7_dev) {
-      hipError_t e = hipFuncSetAttribute((const void*)flash_attn_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W64_LDS);
-      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
-      attr7_dev = dev;
-    }
-    hipLaunchKernelGGL(flash_attn_w64_kernel, grid, dim3(256), W64_LDS, (hipStream_t)stream, p);
   } else if (variant == 5) {
     hipLaunchKernelGGL(flash_attn_kernel<5>, grid, dim3(320), FA_LDS, (hipStream_t)stream, p);
   } else {
