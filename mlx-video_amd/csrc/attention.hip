@@ -177,8 +177,10 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) load_k(kfr[(g + 1) & 1], g + 1);
-        if (KS == 1) issue_k(g, tn, stn);
-        else { issue_k(2 * g, tn, stn); issue_k(2 * g + 1, tn, stn); }
+        // both operands of the next tile are requested during QK^T, as early in the tile as the ring allows (its K and
+        // V^T halves were last read one tile ago): pieces issued during P.V had only ~0.3 us to land before the wait
+        if (KS == 1) { issue_k(g, tn, stn); issue_v(g, tn, stn); }
+        else { issue_k(2 * g, tn, stn); issue_k(2 * g + 1, tn, stn); issue_v(2 * g, tn, stn); issue_v(2 * g + 1, tn, stn); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -253,7 +255,6 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       if (db + 1 < 4) load_v(vfr[(db + 1) & 1], db + 1);
-      issue_v(db, tn, stn);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kbi = 0; kbi < NKB; ++kbi)
