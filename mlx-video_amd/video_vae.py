@@ -408,7 +408,7 @@ class LTX2VideoDecoder:
             if on_frames_ready is not None:
                 try:
                     on_frames_ready(out, 0)
-                except Exception:
+                except Exception:        # the reference swallows callback errors here (decoder.py:514-518)
                     pass
             return out
         return decode_with_tiling(self, sample, tiling_config, 32, 8, causal, timestep, False, on_frames_ready)
