@@ -82,8 +82,12 @@ def precompute_freqs_cis(positions: torch.Tensor, dim: int, theta: float = 10000
     positions (B,3,N,2) float32 on device.  Returns cos, sin (B,H,N,dim/H/2) float32.  The
     per-index frequency vector theta^linspace(0,1,n)*pi/2 (682 floats) is a host table; the
     (N x dim/2) trig table is a HIP kernel."""
+    if positions.dtype == BF16:      # rope.py:433-445: warn, then compute from the (already rounded) values in float32
+        import warnings
+        warnings.warn("Position grid has dtype bfloat16, which causes precision loss in RoPE. "
+                      "Use float32 for position grids to avoid quality degradation.", UserWarning, stacklevel=2)
     if positions.dtype != torch.float32:
-        raise TypeError("position grid must be float32 (rope.py:433-441 warns on bfloat16)")
+        positions = positions.to(torch.float32)
     b, nd, n, two = positions.shape
     if nd != 3 or two != 2:
         raise ValueError(f"positions must be (B,3,N,2), got {tuple(positions.shape)}")

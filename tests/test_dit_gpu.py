@@ -171,3 +171,15 @@ def test_x0_model(dev):
     torch.cuda.synchronize()
     ref = O.BF16.r(lat.float() - ts.float()[..., None] * v.float().cpu())          # utils.py:404-440 per-token sigma
     assert torch.equal(x0.float().cpu(), ref)
+
+
+def test_rope_bf16_positions_match_their_float32_values(dev):
+    """rope.py:433-445: bfloat16 positions warn and are used as float32 of the rounded values."""
+    from mlx_video_amd.ltx_model import precompute_freqs_cis
+    from mlx_video_amd.schedulers import create_position_grid
+    pos = create_position_grid(1, 3, 4, 4).to(dev)
+    with pytest.warns(UserWarning, match="bfloat16"):
+        c1, s1 = precompute_freqs_cis(pos.to(BF), 4096, 10000.0, [20, 2048, 2048], 32)
+    c2, s2 = precompute_freqs_cis(pos.to(BF).float(), 4096, 10000.0, [20, 2048, 2048], 32)
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(s1, s2)

@@ -218,3 +218,20 @@ def test_ffmpeg_writer_contract(tmp_path, monkeypatch):
     monkeypatch.setattr(shutil, "which", lambda name: str(bad))
     with pytest.raises(RuntimeError, match="boom"):
         media.write_video_ffmpeg(frames, tmp_path / "o2.mp4", 24.0)
+
+
+def test_rope_bf16_positions_warn():
+    """test_rope.py:207-221: a bfloat16 position grid triggers the reference's UserWarning (and is then used as
+    float32); float32 grids do not warn.  (The table itself is a HIP kernel: the call fails loudly on CPU tensors.)"""
+    import warnings
+    from mlx_video_amd.ltx_model import precompute_freqs_cis
+    from mlx_video_amd.schedulers import create_position_grid
+    pos = create_position_grid(1, 4, 4, 4)
+    with pytest.warns(UserWarning, match="Position grid has dtype bfloat16"):
+        with pytest.raises(Exception):
+            precompute_freqs_cis(pos.to(torch.bfloat16), 128, 10000.0, [20, 2048, 2048], 32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        with pytest.raises(Exception) as ei:
+            precompute_freqs_cis(pos, 128, 10000.0, [20, 2048, 2048], 32)
+        assert not isinstance(ei.value, UserWarning)
