@@ -229,3 +229,30 @@ def test_lora_merge(dev):
     torch.cuda.synchronize()
     ref = O.BF16.r(w.float() + O.BF16.r(0.7 * (B.float() @ A.float())))
     assert float((merged.float().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+
+
+def test_on_frames_ready_covers_89_frames(dev):
+    """test_vae_streaming.py:159-197 as written there: a mock decoder, temporal_only(32, 8), 12 latent frames ->
+    89 output frames, every frame index handed to the callback."""
+    from mlx_video_amd.video_vae import TilingConfig, decode_with_tiling
+    seen = set()
+    calls = []
+
+    def on_frames_ready(frames, start_idx):
+        calls.append((start_idx, frames.shape[2]))
+        for i in range(frames.shape[2]):
+            seen.add(start_idx + i)
+
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def mock_decoder(x, causal=False, timestep=None, debug=False, chunked_conv=False):
+        b, c, f, h, w = x.shape
+        return torch.randn((b, 3, 1 + (f - 1) * 8, h * 32, w * 32), generator=g, device=dev).to(BF)
+
+    lat = torch.zeros((1, 128, 12, 4, 4), dtype=BF, device=dev)
+    out = decode_with_tiling(mock_decoder, lat, TilingConfig.temporal_only(tile_size=32, overlap=8), 32, 8,
+                             on_frames_ready=on_frames_ready)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 89, 128, 128)
+    assert seen == set(range(89)) and len(calls) >= 2          # streamed in more than one piece, nothing twice
+    assert sum(n for _, n in calls) == 89
