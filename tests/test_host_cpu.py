@@ -235,3 +235,21 @@ def test_rope_bf16_positions_warn():
         with pytest.raises(Exception) as ei:
             precompute_freqs_cis(pos, 128, 10000.0, [20, 2048, 2048], 32)
         assert not isinstance(ei.value, UserWarning)
+
+
+def test_trapezoid_mask_known_properties():
+    """test_vae_streaming.py:223-263 on the host implementation and the oracle: values in [0,1], centre exactly 1,
+    monotonic ramps, temporal masks start from 0, spatial masks start above 0."""
+    from oracle import vae as OV
+    from mlx_video_amd.video_vae import compute_trapezoidal_mask_1d
+    for fn in (compute_trapezoidal_mask_1d, OV.trapezoid_mask):
+        for length in (16, 32, 64, 128):
+            for ramp in (0, 4, 8, 16):
+                if ramp < length:
+                    m = fn(length, ramp, ramp, False).float()
+                    assert float(m.min()) >= 0.0 and float(m.max()) <= 1.0
+        m = fn(32, 8, 8, False).float()
+        assert torch.allclose(m[12:20], torch.ones(8), rtol=1e-5)
+        assert bool((m[1:9] >= m[:8]).all()) and bool((m[-8:] <= m[-9:-1]).all())        # ramps monotonic
+        assert float(fn(32, 8, 0, True)[0]) == 0.0                                          # temporal: starts from 0
+        assert float(fn(32, 8, 0, False)[0]) > 0.0                                          # spatial: starts above 0
