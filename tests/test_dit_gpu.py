@@ -183,3 +183,21 @@ def test_rope_bf16_positions_match_their_float32_values(dev):
     c2, s2 = precompute_freqs_cis(pos.to(BF).float(), 4096, 10000.0, [20, 2048, 2048], 32)
     torch.cuda.synchronize()
     assert torch.equal(c1, c2) and torch.equal(s1, s2)
+
+
+def test_rope_float32_consistent_and_bf16_loses_precision(dev):
+    """test_rope.py:31-125 on the HIP table: float32 positions give finite cos/sin in [-1,1] of shape (1,32,N,2) at
+    dim=128; bfloat16 positions give measurably different values (the precision loss the reference documents)."""
+    import warnings
+    from mlx_video_amd.ltx_model import precompute_freqs_cis
+    from mlx_video_amd.schedulers import create_position_grid
+    pos = create_position_grid(1, 4, 4, 4).to(dev)
+    c32, s32 = precompute_freqs_cis(pos, 128, 10000.0, [20, 2048, 2048], 32)
+    assert tuple(c32.shape) == (1, 32, 64, 2) and c32.dtype == torch.float32
+    for t in (c32, s32):
+        assert bool(torch.isfinite(t).all()) and float(t.min()) >= -1.0 and float(t.max()) <= 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c16, s16 = precompute_freqs_cis(pos.to(BF), 128, 10000.0, [20, 2048, 2048], 32)
+    torch.cuda.synchronize()
+    assert max(float((c32 - c16).abs().max()), float((s32 - s16).abs().max())) > 1e-6
