@@ -36,16 +36,16 @@ def test_position_grid_matches_oracle_and_bounds(b, f, h, w, fps):
 
 
 @settings(**SET)
-@given(steps=st.integers(1, 60), tokens=st.one_of(st.none(), st.integers(1, 9000)))
-def test_scheduler_matches_oracle_and_invariants(steps, tokens):
-    got = S.ltx2_scheduler(steps, tokens)
-    ref = OS.ltx2_scheduler(steps, tokens)
+@given(steps=st.integers(1, 60), tokens=st.one_of(st.none(), st.integers(1, 9000)), stretch=st.booleans())
+def test_scheduler_matches_oracle_and_invariants(steps, tokens, stretch):
+    got = S.ltx2_scheduler(steps, tokens, stretch=stretch)
+    ref = OS.ltx2_scheduler(steps, tokens, stretch=stretch)
     g = np.asarray(got, dtype=np.float64)
     assert g.shape == (steps + 1,)
     np.testing.assert_allclose(g, np.asarray(ref, dtype=np.float64), rtol=0, atol=1e-6)
-    assert abs(g[0] - 1.0) < 1e-6 and g[-1] == 0.0                      # test_generate_dev.py:21-40
+    assert abs(g[0] - 1.0) < 1e-6 and g[-1] == 0.0                      # test_generate_dev.py:21-40, 59-64 (no stretch)
     assert np.all(np.diff(g) < 0)                                       # strictly decreasing
-    if steps > 1:
+    if steps > 1 and stretch:
         assert abs(g[-2] - 0.1) < 1e-5                                  # stretched so the last non-zero sigma is 0.1
 
 
