@@ -144,16 +144,27 @@ int ltxk_latent_to_tokens(const void* latent, void* tokens, int32_t B, int32_t C
  *   v_pos/v_neg: (B,S,C) bf16 velocities (v_neg NULL => no CFG)
  *   latent/out : (B,C,S) bf16;  clean: (B,C,S) bf16 or NULL;  mask: (B,S) float or NULL
  *   x0  = bf16(x - sigma*v);  x0 = x0*m + clean*(1-m);  out = bf16(x0 + sigma_next*(x-x0)/sigma)
- *   sigma_next <= 0 => out = x0.                                                         */
+ *   sigma_next <= 0 => out = x0.
+ *   flags & LTXK_STEP_BF16_EULER: the Euler update runs op by op in bf16, the reference's
+ *   fp32_euler=False / LTX_FP32_EULER=0 compiled step (generate.py:741-748):
+ *   out = bf16(x0 + bf16(bf16(sigma_next * bf16(x - x0)) / sigma)).                        */
+enum { LTXK_STEP_BF16_EULER = 1 };
 int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent, void* out,
                         const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
-                        float cfg_scale, float sigma, float sigma_next, void* stream);
+                        float cfg_scale, float sigma, float sigma_next, int32_t flags, void* stream);
 
 /* Same step tail with {sigma, sigma_next} read from DEVICE memory (2 floats): lets one captured
  * hipGraph of the whole denoise step be replayed for every step of the schedule.           */
 int ltxk_cfg_euler_step_dev(const void* v_pos, const void* v_neg, const void* latent, void* out,
                             const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
-                            float cfg_scale, const float* sigmas_dev, void* stream);
+                            float cfg_scale, const float* sigmas_dev, int32_t flags, void* stream);
+
+/* Per-step scalars of a replayed step graph: with s = min(*step, n_steps-1), copies ts_all[s,:] (U bf16
+ * timestep values = bf16(sigma_s)*mask, generate.py:1084,1237) to ts and sig_all[s,:] ({sigma, sigma_next}
+ * fp32) to sig, then stores *step = s+1.  As the first node of a captured denoise step it lets the whole
+ * schedule run as graph replays with no host->device traffic between steps.               */
+int ltxk_step_scalars(const void* ts_all, const float* sig_all, int32_t* step, void* ts, float* sig,
+                      int32_t U, int32_t n_steps, void* stream);
 
 /* Euler update alone (eager path, generate.py:1293-1301, with un-rounded float sigmas):
  * out = bf16(x0 + sigma_next*(x - x0)/sigma) in fp32; n elements, any layout.             */
@@ -181,6 +192,10 @@ typedef struct ltxk_conv3d_args {
    * Partial slabs are written with plain stores and summed in slice order, so results are deterministic. */
   void* workspace;
   int64_t workspace_bytes;
+  /* temporal taps: 0 or 3 = the 3x3x3 kernel; 1 = a per-frame 3x3 kernel, w = (Cout,3,3,Cin) (the latent
+   * upsampler's nn.Conv2d applied frame by frame, upsampler.py:64-99): only the centre temporal tap exists,
+   * K = 9*Cin instead of 27*Cin.                                                                        */
+  int32_t taps_d;
 } ltxk_conv3d_args;
 
 /* nn.Conv3d 3x3x3 stride 1 inside CausalConv3d (convolution.py:78-222) as implicit GEMM.   */

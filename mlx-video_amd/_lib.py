@@ -31,7 +31,7 @@ class Conv3dArgs(Structure):
         ("B", c_int32), ("D", c_int32), ("H", c_int32), ("W", c_int32),
         ("Cin", c_int32), ("Cout", c_int32),
         ("causal", c_int32), ("pad_mode", c_int32),
-        ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64), ("taps_d", c_int32),
     ]
 
 
@@ -73,11 +73,12 @@ SIGNATURES = {
                                      c_float, c_int32, c_void_p]),
     "ltxk_tile_blend_accum": (c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 8 + [c_void_p]),
     "ltxk_tile_blend_finalize": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int64, c_void_p]),
+    "ltxk_step_scalars": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "ltxk_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "ltxk_cfg_euler_step_dev": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                          c_int32, c_float, c_void_p, c_void_p]),
+                                          c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "ltxk_cfg_euler_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32,
-                                      c_int32, c_float, c_float, c_float, c_void_p]),
+                                      c_int32, c_float, c_float, c_float, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -20,6 +20,7 @@ struct ConvParams {
   int M, RT, CT, cpb;   // cpb = Cin/64 K-steps per tap
   float* slab;          // split-K: fp32 partial slabs [S][M][Cout] (plain stores, summed in slice order)
   int S, kper;          // K slices per tile, K-steps per slice
+  int ntaps, kd0;       // 27 taps from kd=0, or 9 taps at kd0=1 (per-frame 3x3 kernel)
 };
 
 template <int TT, int WN, bool RES, bool SPLIT>
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   const int slice = SPLIT ? blockIdx.x - tile * p.S : 0;
   const int ct = tile % p.CT, rt = tile / p.CT;
   const int m0 = rt * G::BM, n0 = ct * G::BN;
-  const int K = 27 * p.Cin;
+  const int K = p.ntaps * p.Cin;
 
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   unsigned off_tap[G::MAXA];
   bool ztap[G::MAXA];
   auto set_tap = [&](int tap) __attribute__((always_inline)) {
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    const int kd = p.kd0 + tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
     // 3-way selects as scalar bit masks (a ?: chain is turned into a scratch-memory table lookup by hipcc)
     const unsigned d0 = kd == 0 ? ~0u : 0u, d1 = kd == 1 ? ~0u : 0u, d2 = kd == 2 ? ~0u : 0u;
     const unsigned h0 = kh == 0 ? ~0u : 0u, h1 = kh == 1 ? ~0u : 0u, h2 = kh == 2 ? ~0u : 0u;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // this workgroup's K-step range [kbeg, nk) (the whole K unless split)
-  const int nk_all = 27 * p.cpb;
+  const int nk_all = p.ntaps * p.cpb;
   const int kbeg = SPLIT ? slice * p.kper : 0;
   int nk = SPLIT ? kbeg + p.kper : nk_all;
   nk = nk < nk_all ? nk : nk_all;
@@ -268,7 +269,7 @@ static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspac
   ConvParams p = p0;
   p.RT = (p.M + G::BM - 1) / G::BM;
   p.CT = (p.Cout + G::BN - 1) / G::BN;
-  const int tiles = p.RT * p.CT, nk = 27 * p.cpb;
+  const int tiles = p.RT * p.CT, nk = p.ntaps * p.cpb;
   // split K when the tile grid leaves most of the 256 CUs idle (the 1024/512-channel stages of the decoder
   // have only 1280 / 9216 voxels): S slices of >= 16 K-steps, fp32 slabs in the caller's workspace.
   int S = 1;
@@ -335,6 +336,8 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.resid = (const bf16*)a->resid; p.zero = (const bf16*)a->zero_page;
   p.B = a->B; p.D = a->D; p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.Cout = a->Cout;
   p.causal = a->causal; p.pad_mode = a->pad_mode; p.M = (int)M; p.cpb = a->Cin / 64; p.RT = p.CT = 0;
+  LTXK_CHECK_ARG(a->taps_d == 0 || a->taps_d == 3 || a->taps_d == 1, "ltxk_conv3d_k3_bf16: taps_d must be 3 (or 0) or 1, got %d", a->taps_d);
+  p.ntaps = a->taps_d == 1 ? 9 : 27; p.kd0 = a->taps_d == 1 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const bool res = a->resid != nullptr;
   float* ws = (float*)a->workspace;

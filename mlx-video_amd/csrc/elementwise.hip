@@ -235,7 +235,7 @@ __global__ void cfg_euler_kernel(const bf16* __restrict__ vp, const bf16* __rest
                                  const bf16* __restrict__ lat, bf16* __restrict__ out,
                                  const bf16* __restrict__ clean, const float* __restrict__ mask,
                                  int B, int C, int S, float cfg, float sigma, float sigma_next,
-                                 const float* __restrict__ sig_dev) {
+                                 const float* __restrict__ sig_dev, int flags) {
   if (sig_dev) {            // graph replay: the two scalars live in device memory
     sigma = sig_dev[0];
     sigma_next = sig_dev[1];
@@ -258,7 +258,10 @@ __global__ void cfg_euler_kernel(const bf16* __restrict__ vp, const bf16* __rest
     float x0 = rbf(x - sigma * v);
     if (mask) x0 = rbf(rbf(x0 * m) + rbf((float)clean[li] * rbf(1.0f - m)));
     float o = x0;
-    if (sigma_next > 0.f) {
+    if (flags & LTXK_STEP_BF16_EULER) {
+      // fp32_euler=False (generate.py:748): every op of x0 + s'*(x - x0)/s materialises a bf16 array
+      o = x0 + rbf(__fdiv_rn(rbf(sigma_next * rbf(x - x0)), sigma));
+    } else if (sigma_next > 0.f) {
       const float t1 = x - x0;
       const float t2 = sigma_next * t1;
       o = x0 + __fdiv_rn(t2, sigma);
@@ -282,9 +285,30 @@ __global__ void euler_kernel(const bf16* __restrict__ x, const bf16* __restrict_
   *(bf16x8*)(out + idx * 8) = o;
 }
 
+// One wave.  Row *step of the per-step scalar tables -> the buffers the step's kernels read; *step += 1.
+__global__ void step_scalars_kernel(const bf16* __restrict__ ts_all, const float* __restrict__ sig_all,
+                                    int32_t* __restrict__ step, bf16* __restrict__ ts, float* __restrict__ sig,
+                                    int U, int n_steps) {
+  int s = *step;
+  s = s < n_steps ? s : n_steps - 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < U; i += blockDim.x) ts[i] = ts_all[(size_t)s * U + i];
+  if (threadIdx.x < 2) sig[threadIdx.x] = sig_all[2 * s + threadIdx.x];
+  if (threadIdx.x == 0) *step = s + 1;
+}
+
 }  // namespace ltxk
 
 using namespace ltxk;
+
+extern "C" int ltxk_step_scalars(const void* ts_all, const float* sig_all, int32_t* step, void* ts, float* sig,
+                                 int32_t U, int32_t n_steps, void* stream) {
+  LTXK_CHECK_ARG(ts_all && sig_all && step && ts && sig && U > 0 && n_steps > 0, "ltxk_step_scalars: bad arguments");
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)ts_all, sig_all, step,
+                     (bf16*)ts, sig, U, n_steps);
+  LTXK_CHECK_LAUNCH("ltxk_step_scalars");
+  return LTXK_OK;
+}
 
 extern "C" int ltxk_euler_step(const void* latent, const void* denoised, void* out, int64_t n,
                                float sigma, float sigma_next, void* stream) {
@@ -396,28 +420,28 @@ extern "C" int ltxk_latent_to_tokens(const void* latent, void* tokens, int32_t B
 
 static int cfg_euler_launch(const void* v_pos, const void* v_neg, const void* latent, void* out, const void* clean,
                             const float* mask, int32_t B, int32_t C, int32_t S, float cfg_scale, float sigma,
-                            float sigma_next, const float* sig_dev, void* stream, const char* name) {
+                            float sigma_next, const float* sig_dev, int32_t flags, void* stream, const char* name) {
   LTXK_CHECK_ARG(v_pos && latent && out && B > 0 && S > 0 && C > 0 && C % 8 == 0, "%s: bad arguments", name);
   LTXK_CHECK_ARG((clean == nullptr) == (mask == nullptr), "%s: clean and mask must both be set or both NULL", name);
   LTXK_CHECK_ARG(sig_dev != nullptr || sigma > 0.f, "%s: sigma must be > 0", name);
   hipLaunchKernelGGL(cfg_euler_kernel, dim3((S + 63) / 64, C / 8, B), dim3(64), 0, (hipStream_t)stream,
                      (const bf16*)v_pos, (const bf16*)v_neg, (const bf16*)latent, (bf16*)out, (const bf16*)clean, mask,
-                     B, C, S, cfg_scale, sigma, sigma_next, sig_dev);
+                     B, C, S, cfg_scale, sigma, sigma_next, sig_dev, (int)flags);
   LTXK_CHECK_LAUNCH(name);
   return LTXK_OK;
 }
 
 extern "C" int ltxk_cfg_euler_step(const void* v_pos, const void* v_neg, const void* latent, void* out,
                                    const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
-                                   float cfg_scale, float sigma, float sigma_next, void* stream) {
-  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, sigma, sigma_next, nullptr, stream,
+                                   float cfg_scale, float sigma, float sigma_next, int32_t flags, void* stream) {
+  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, sigma, sigma_next, nullptr, flags, stream,
                           "ltxk_cfg_euler_step");
 }
 
 extern "C" int ltxk_cfg_euler_step_dev(const void* v_pos, const void* v_neg, const void* latent, void* out,
                                        const void* clean, const float* mask, int32_t B, int32_t C, int32_t S,
-                                       float cfg_scale, const float* sigmas_dev, void* stream) {
+                                       float cfg_scale, const float* sigmas_dev, int32_t flags, void* stream) {
   LTXK_CHECK_ARG(sigmas_dev != nullptr, "ltxk_cfg_euler_step_dev: null sigmas_dev");
-  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, 1.f, 0.f, sigmas_dev, stream,
+  return cfg_euler_launch(v_pos, v_neg, latent, out, clean, mask, B, C, S, cfg_scale, 1.f, 0.f, sigmas_dev, flags, stream,
                           "ltxk_cfg_euler_step_dev");
 }

@@ -108,22 +108,42 @@ def _resolve_frame_idx(frame_idx: int, num_frames: int, latent_frames: int) -> i
     return int(max(0, min(latent_frames - 1, int((frame_idx / (num_frames - 1) * (latent_frames - 1)) + 0.5))))
 
 
+def _cond_pixels(src, height: int, width: int, is_video: bool, num_frames: int) -> torch.Tensor:
+    """One conditioning source at one stage's resolution -> (1,3,F,height,width) in [-1,1] (host tensor).
+    Paths go through media.load_image / load_frames (utils.py:529-613: LANCZOS for images, INTER_AREA-like box
+    filter for video frames, frame_cap=num_frames); pixel tensors (1,3,F,H,W) in [-1,1] of another size are
+    resized the way prepare_image_for_encoding / prepare_video_for_encoding do (utils.py:643-715: through uint8)."""
+    from . import media
+    if isinstance(src, (str, Path)):
+        if is_video:
+            return media.frames_to_conditioning(media.load_frames(src, height, width, frame_cap=num_frames))
+        return media.image_to_conditioning(media.load_image(src, height=height, width=width))
+    if isinstance(src, np.ndarray):
+        src = torch.from_numpy(src)
+    if not torch.is_tensor(src) or src.dim() != 5 or src.shape[1] != 3:
+        raise ValueError("conditioning source must be a path, or a (1,3,F,H,W) pixel tensor in [-1,1]")
+    t = src.detach().to("cpu", torch.float32)
+    if is_video:
+        t = t[:, :, :num_frames]
+        t = t[:, :, : 1 + ((t.shape[2] - 1) // 8) * 8]            # the encoder takes 1+8k frames (video_vae.py:332-337)
+    if tuple(t.shape[-2:]) == (height, width):
+        return t
+    frames01 = ((t[0].permute(1, 2, 3, 0) + 1.0) / 2.0).clamp(0, 1).numpy()        # (F,H,W,3) in [0,1]
+    return media.resize_conditioning(frames01, height, width, is_video)
+
+
 def _encode_conditionings(items, encoder: Optional[VideoEncoder], height: int, width: int, num_frames: int,
-                          latent_frames: int, guide: bool, device):
-    """items: (pixels (1,3,F,H,W) in [-1,1] | latent (1,128,f,h,w), frame_idx, strength).  Pixel
-    tensors are encoded with the VAE encoder at the stage's resolution (generate.py:3064-3113)."""
+                          latent_frames: int, guide: bool, device, is_video: bool = False):
+    """items: (path | pixels (1,3,F,H,W) in [-1,1] | latent (1,128,f,h,w), frame_idx, strength).  Pixels are
+    brought to the stage's resolution and encoded with the VAE encoder (generate.py:3064-3113)."""
     out = []
     for src, frame_idx, strength in items:
-        if not torch.is_tensor(src):
-            raise ValueError("image/video conditioning must be given as tensors (file decoding via cv2/PIL is "
-                             "conditioning-input I/O, SURVEY.md §8f row 4)")
-        t = src.to(device)
-        if t.shape[1] == 3:
+        if torch.is_tensor(src) and src.dim() == 5 and src.shape[1] == 128:
+            t = src.to(device).to(BF16)                                             # already a latent
+        else:
             if encoder is None:
-                raise ValueError("pixel conditioning needs a VAE encoder (pass vae_encoder=)")
-            if tuple(t.shape[-2:]) != (height, width):
-                raise ValueError(f"conditioning frames must already be {width}x{height}, got {t.shape[-1]}x{t.shape[-2]}")
-            t = encoder(t.to(BF16))
+                raise ValueError("pixel conditioning needs a VAE encoder (pass vae_encoder= or a model_repo with VAE encoder weights)")
+            t = encoder(_cond_pixels(src, height, width, is_video, num_frames).to(device).to(BF16))
         idx = _resolve_frame_idx(int(frame_idx), num_frames, latent_frames)
         out.append(VideoConditionByKeyframeIndex(t, idx, float(strength)) if guide
                    else VideoConditionByLatentIndex(t, idx, float(strength)))
@@ -144,6 +164,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
                    sigma_subsample: str = "farthest",
                    # ---- injected in place of what the reference downloads / samples ----
                    transformer: Optional[LTXModel] = None, stage2_transformer: Optional[LTXModel] = None,
+                   transformer_weights: Optional[Dict[str, torch.Tensor]] = None, transformer_config: Optional[LTXModelConfig] = None,
                    vae_decoder: Optional[LTX2VideoDecoder] = None, vae_encoder: Optional[VideoEncoder] = None,
                    upsampler=None, prompt_embeds: Optional[torch.Tensor] = None,
                    negative_prompt_embeds: Optional[torch.Tensor] = None, text_encoder: Optional[Callable] = None,
@@ -178,14 +199,36 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
     num_frames = _round_frames(num_frames)
     latent_frames = 1 + (num_frames - 1) // 8
 
-    if transformer is None:
+    if is_distilled:                                               # generate.py:3054-3057
+        if stage1_steps < 1 or stage1_steps > (len(STAGE_1_SIGMAS) - 1):
+            raise ValueError("--stage1-steps must be between 1 and 8.")
+        if stage2_steps not in (1, 2, 3):
+            raise ValueError("--stage2-steps must be 1, 2, or 3.")
+    if stage2_transformer is not None and distilled_loras:          # generate.py:3210-3211
+        raise ValueError("--stage2-model-repo cannot be combined with --distilled-lora (stage-2 LoRA).")
+
+    def _with_loras(lora_list, what: str) -> LTXModel:
+        """generate.py:2957-3031 (_load_transformer_with_loras), merge mode: base weights + the listed LoRAs."""
+        if transformer_weights is None:
+            raise ValueError(f"{what} were given but the base transformer weights are not reachable: pass "
+                             "transformer_weights= (the dict the transformer was built from) or a model_repo")
+        from .lora import LoraSpec, apply_lora_to_weights
+        merged = apply_lora_to_weights(transformer_weights, [LoraSpec(Path(pth), float(st)) for pth, st in lora_list], verbose=verbose)
+        return LTXModel(transformer_config or (transformer.config if transformer is not None else LTXModelConfig()), merged)
+
+    if transformer is None and transformer_weights is None:
         if model_repo is None:
             raise FileNotFoundError("no transformer: pass transformer= or a local model_repo directory with LTX-2 safetensors")
         from .weights import load_pipeline_modules
-        mods = load_pipeline_modules(model_repo, device, need_encoder=bool(images_list or video_conditionings),
-                                     need_upsampler=is_distilled, loras=loras)
-        transformer, vae_decoder = mods["transformer"], vae_decoder or mods["vae_decoder"]
+        mods = load_pipeline_modules(model_repo, device or torch.device("cuda:0"), need_encoder=bool(images_list or video_conditionings),
+                                     need_upsampler=is_distilled, build_transformer=False)
+        transformer_weights, transformer_config = mods["transformer_weights"], mods["transformer_config"]
+        vae_decoder = vae_decoder or mods["vae_decoder"]
         vae_encoder, upsampler = vae_encoder or mods.get("vae_encoder"), upsampler or mods.get("upsampler")
+    if loras:
+        transformer = _with_loras(loras, "loras")                  # stage 1 / dev: base + loras
+    elif transformer is None:
+        transformer = LTXModel(transformer_config or LTXModelConfig(), transformer_weights)
     if vae_decoder is None:
         raise FileNotFoundError("no VAE decoder: pass vae_decoder= or a model_repo containing VAE weights")
     dev = device or transformer.tables.device
@@ -217,35 +260,29 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         s1h, s1w, s2h, s2w = height // 2 // 32, width // 2 // 32, height // 32, width // 32
         sig1 = _subsample_sigmas(list(STAGE_1_SIGMAS), stage1_steps, sigma_subsample)
         sig2 = _subsample_refinement_sigmas(list(STAGE_2_SIGMAS), stage2_steps, sigma_subsample)
-        cond_items = images_list + video_conditionings
         conds1, conds2 = [], []
-        if cond_items:
+        if images_list or video_conditionings:
             with timer.phase("cond_encode"):
-                # the reference loads each file twice, resized to the half- and full-resolution stage
-                # (generate.py:3064-3113); with tensors the half-resolution copy is an antialiased resample
-                # (conditioning-input preprocessing, not part of the denoise/VAE hot path)
-                import torch.nn.functional as F
-                half = []
-                for src, fi, st_ in cond_items:
-                    if src.shape[1] != 3:
-                        raise ValueError("two-stage pipelines take pixel conditionings (encoded at both resolutions)")
-                    b_, c_, f_, h_, w_ = src.shape
-                    hs = F.interpolate(src.float().permute(0, 2, 1, 3, 4).reshape(b_ * f_, c_, h_, w_), size=(height // 2, width // 2),
-                                       mode="bilinear", antialias=True, align_corners=False)
-                    half.append((hs.reshape(b_, f_, c_, height // 2, width // 2).permute(0, 2, 1, 3, 4).contiguous(), fi, st_))
-                conds1 = _encode_conditionings(half, vae_encoder, height // 2, width // 2, num_frames, latent_frames, guide, dev)
-                conds2 = _encode_conditionings(cond_items, vae_encoder, height, width, num_frames, latent_frames, guide, dev)
+                # every image is encoded twice, at the half- and the full-resolution stage, with the chosen mode;
+                # a video conditioning (IC-LoRA) guides stage 1 only, always as keyframes (generate.py:3073-3110)
+                conds1 = _encode_conditionings(images_list, vae_encoder, height // 2, width // 2, num_frames, latent_frames, guide, dev)
+                conds2 = _encode_conditionings(images_list, vae_encoder, height, width, num_frames, latent_frames, guide, dev)
+                conds1 += _encode_conditionings(video_conditionings, vae_encoder, height // 2, width // 2, num_frames, latent_frames,
+                                                True, dev, is_video=True)
         shape1 = (1, 128, latent_frames, s1h, s1w)
         pos1 = create_position_grid(1, latent_frames, s1h, s1w, fps=fps).to(dev)
         state1 = init_state(shape1, conds1, sig1[0]) if conds1 else None
         latents = state1.latent if state1 is not None else noise_fn(shape1)
         with timer.phase("stage1_denoise"):
             latents, _ = denoise_distilled(latents, pos1, ctx_pos, transformer, sig1, state=state1,
-                                           compile_step=compile_step, fp32_euler=fp32_euler)
+                                           compile_step=compile_step, fp32_euler=fp32_euler, use_graph=compile_step)
         with timer.phase("upsample"):
             from .upsampler import upsample_latents
             latents = upsample_latents(latents, upsampler, vae_decoder.latents_mean, vae_decoder.latents_std)
         tr2 = stage2_transformer or transformer
+        if distilled_loras:                                          # generate.py:3229-3237: base + distilled LoRAs only
+            with timer.phase("stage2_transformer_load"):
+                tr2 = _with_loras(distilled_loras, "distilled_loras")
         pos2 = create_position_grid(1, latent_frames, s2h, s2w, fps=fps).to(dev)
         state2 = None
         if conds2:                                                  # generate.py:3290-3311
@@ -258,10 +295,10 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         with timer.phase("stage2_denoise"):
             if stage2_dev:
                 latents = denoise_dev(latents, pos2, ctx_pos, ctx_neg, tr2, torch.tensor(sig2), cfg_scale=cfg_scale,
-                                      state=state2, compile_step=compile_step, cfg_batch=cfg_batch)
+                                      state=state2, compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step)
             else:
                 latents, _ = denoise_distilled(latents, pos2, ctx_pos, tr2, sig2, state=state2, compile_step=compile_step,
-                                               fp32_euler=fp32_euler)
+                                               fp32_euler=fp32_euler, use_graph=compile_step)
     else:
         lh, lw = height // 32, width // 32
         n_tok = latent_frames * lh * lw
@@ -276,7 +313,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         latents = state.latent if state is not None else noise_fn(shape)
         with timer.phase("dev_denoise"):
             latents = denoise_dev(latents, pos, ctx_pos, ctx_neg, transformer, sigmas, cfg_scale=cfg_scale, state=state,
-                                  compile_step=compile_step, cfg_batch=cfg_batch)
+                                  compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step)
 
     if return_latents:
         return latents
@@ -288,14 +325,16 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         tcfg = {"default": TilingConfig.default, "aggressive": TilingConfig.aggressive,
                 "conservative": TilingConfig.conservative, "spatial": TilingConfig.spatial_only,
                 "temporal": TilingConfig.temporal_only}[tiling]()
-    dec_noise = noise_fn(tuple(latents.shape)) if vae_decoder.timestep_conditioning else None
+    # a timestep-conditioned decoder draws fresh noise per decode call, i.e. per tile (decoder.py:381-385)
+    dec_noise_fn = noise_fn if vae_decoder.timestep_conditioning else None
     with timer.phase("vae_decode"):
         if tcfg is not None and (tiling != "auto" or stream):
-            video = vae_decoder.decode_tiled(latents, tiling_config=tcfg, tiling_mode=tiling, on_frames_ready=on_frames_ready)
+            video = vae_decoder.decode_tiled(latents, tiling_config=tcfg, tiling_mode=tiling, on_frames_ready=on_frames_ready,
+                                             noise_fn=dec_noise_fn)
         else:
             # "auto": the reference first tries the non-tiled decode and only falls back on an OOM-looking
             # exception (generate.py:3798-3818); 288 GB of HBM never takes that fallback at these sizes.
-            video = vae_decoder(latents, noise=dec_noise) if dec_noise is not None else vae_decoder(latents)
+            video = vae_decoder(latents, noise_fn=dec_noise_fn)
     with timer.phase("to_uint8_numpy"):
         frames = to_uint8_frames(video)[0]
         video_np = frames.cpu().numpy()
@@ -326,9 +365,56 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
     return video_np
 
 
+class _ImageConditionAction(argparse.Action):
+    """generate.py:4201-4215: --image PATH [FRAME_IDX STRENGTH], repeatable."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        if len(values) not in (1, 3):
+            raise argparse.ArgumentError(self, f"{option_string} accepts 1 or 3 args (PATH [FRAME_IDX STRENGTH]), got {len(values)}")
+        item = (values[0], int(values[1]), float(values[2])) if len(values) == 3 else (values[0], None, None)
+        setattr(namespace, self.dest, (getattr(namespace, self.dest) or []) + [item])
+
+
+class _VideoConditionAction(argparse.Action):
+    """generate.py:4217-4231: --video-conditioning PATH STRENGTH | PATH FRAME_IDX STRENGTH, repeatable."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        if len(values) not in (2, 3):
+            raise argparse.ArgumentError(self, f"{option_string} accepts PATH STRENGTH or PATH FRAME_IDX STRENGTH")
+        item = (values[0], 0, float(values[1])) if len(values) == 2 else (values[0], int(values[1]), float(values[2]))
+        setattr(namespace, self.dest, (getattr(namespace, self.dest) or []) + [item])
+
+
+class _LoraAction(argparse.Action):
+    """generate.py:4233-4242: --lora PATH [STRENGTH], repeatable."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        if len(values) not in (1, 2):
+            raise argparse.ArgumentError(self, f"{option_string} accepts PATH or PATH STRENGTH, got {len(values)}")
+        item = (values[0], float(values[1]) if len(values) == 2 else 1.0)
+        setattr(namespace, self.dest, (getattr(namespace, self.dest) or []) + [item])
+
+
 def build_parser() -> argparse.ArgumentParser:
     """The subset of generate.py:4244-4525 that drives this path."""
     ap = argparse.ArgumentParser(description="LTX-2 video generation on MI355X (libltxk)")
+    ap.add_argument("--image", "-i", action=_ImageConditionAction, nargs="+", metavar="PATH", default=[],
+                    help="Image conditioning: --image path.jpg or --image path.jpg FRAME_IDX STRENGTH (repeatable)")
+    ap.add_argument("--condition-image", type=str, default=None, help="Alias for --image (frame 0, strength 1.0)")
+    ap.add_argument("--image-strength", type=float, default=1.0)
+    ap.add_argument("--image-frame-idx", type=int, default=0)
+    ap.add_argument("--video-conditioning", action=_VideoConditionAction, nargs="+", metavar="ARG", default=[],
+                    help="Video conditioning for IC-LoRA: PATH [FRAME_IDX] STRENGTH (a directory of frames or an .npy array here)")
+    ap.add_argument("--reference-video", type=str, default=None, help="Alias for --video-conditioning (frame 0, strength 1.0)")
+    ap.add_argument("--lora", "--lora-path", dest="lora", action=_LoraAction, nargs="+", metavar="ARG", default=[],
+                    help="LoRA weights to merge (repeatable): --lora path 0.8")
+    ap.add_argument("--distilled-lora", action=_LoraAction, nargs="+", metavar="ARG", default=[],
+                    help="LoRA(s) for stage-2 refinement (distilled pipelines only)")
+    ap.add_argument("--conditioning-mode", choices=["replace", "guide"], default="replace")
+    ap.add_argument("--stream", action="store_true", help="Decode tiled and hand frames over as they are finished")
+    ap.add_argument("--stage2-dev", action="store_true")
+    ap.add_argument("--no-fp32-euler", dest="fp32_euler", action="store_false",
+                    default=__import__("os").getenv("LTX_FP32_EULER", "").lower() not in ("0", "false", "no"))
     ap.add_argument("--prompt", type=str, default="")
     ap.add_argument("--negative-prompt", type=str, default=DEFAULT_NEGATIVE_PROMPT)
     ap.add_argument("--pipeline", choices=[p.value for p in PipelineType], default="distilled")
@@ -370,6 +456,13 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
         args.cfg_batch = is_dev and args.cfg_scale > 1.0
     dev = torch.device("cuda:0")
     kw = {}
+    # generate.py:4667-4694: --image items without an explicit index/strength take --image-frame-idx / --image-strength
+    images = [(pth, args.image_frame_idx if fi is None else fi, args.image_strength if st is None else st) for pth, fi, st in args.image]
+    if args.condition_image:
+        images.append((args.condition_image, 0, 1.0))
+    videos = list(args.video_conditioning)
+    if args.reference_video:
+        videos.append((args.reference_video, 0, 1.0))
     if args.synthetic:
         from .video_vae import random_decoder_weights
         kw["transformer"] = LTXModel.random_init(LTXModelConfig(num_layers=args.layers), dev)
@@ -381,6 +474,9 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
             from .upsampler import LatentUpsampler
             from .weights import random_upsampler_weights
             kw["upsampler"] = LatentUpsampler(random_upsampler_weights(dev))
+        if images or videos:
+            from .video_vae import random_encoder_weights
+            kw["vae_encoder"] = VideoEncoder(random_encoder_weights(dev))
     else:
         def _load(path):
             return torch.from_numpy(np.load(path)) if path.endswith(".npy") else torch.load(path, weights_only=True)
@@ -393,7 +489,10 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
                    num_inference_steps=args.steps, cfg_scale=args.cfg_scale, seed=args.seed, fps=args.fps,
                    output_path=args.output_path, tiling=args.tiling, compile_step=args.compile_step, cfg_batch=args.cfg_batch,
                    profile=args.profile, profile_json_path=args.profile_json, stage1_steps=args.stage1_steps,
-                   stage2_steps=args.stage2_steps, sigma_subsample=args.sigma_subsample, verbose=True, device=dev, **kw)
+                   stage2_steps=args.stage2_steps, sigma_subsample=args.sigma_subsample, verbose=True, device=dev,
+                   images=images, video_conditionings=videos, loras=args.lora, distilled_loras=args.distilled_lora,
+                   conditioning_mode=args.conditioning_mode, stream=args.stream, stage2_dev=args.stage2_dev,
+                   fp32_euler=args.fp32_euler, **kw)
 
 
 if __name__ == "__main__":

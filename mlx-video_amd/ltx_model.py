@@ -107,6 +107,18 @@ class _Block:
                  "wqn2", "wkn2", "wo2", "bo2", "w1", "b1", "w2", "b2")
 
 
+class ContextKV:
+    """Step-invariant text-side tensors of ONE context: the caption projection (ltx.py:77-89) and every
+    block's cross-attention K (q/k-normed) and V^T (attention.py:123-131 with context=text).  Built by
+    ``LTXModel.prepare_context`` and owned by the caller: ``prepare_context(context, out=kv)`` recomputes
+    it IN PLACE for a new prompt, so a captured step graph that reads these buffers stays valid."""
+
+    def __init__(self, shape: Tuple[int, int, int]):
+        self.shape = tuple(shape)           # (B,S,caption_channels) it was built for
+        self.ctx: Optional[torch.Tensor] = None
+        self.kv: List[tuple] = []
+
+
 class LTXModel:
     """Velocity model.  ``model(video=Modality(...)) -> (velocity (B,N,128), None)``."""
 
@@ -119,12 +131,12 @@ class LTXModel:
         self.use_middle_indices_grid = config.use_middle_indices_grid
         self.rope_type = config.rope_type
         self.timestep_scale_multiplier = config.timestep_scale_multiplier
-        self.cache_context = False          # reuse caption projection + ctx K/V across calls (same context tensor)
-        self._ctx_cache: Dict[int, tuple] = {}
         self._pack(weights)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, W: Dict[str, torch.Tensor]) -> None:
+        """Builds the packed panels from ``W`` WITHOUT modifying it (a second model - e.g. the LoRA-merged
+        stage-2 transformer, generate.py:3229-3237 - can be constructed from the same dict)."""
         cfg = self.config
         missing = [k for k in self.expected_keys(cfg) if k not in W]
         if missing:   # strict load (ltx.py:874-881)
@@ -163,8 +175,6 @@ class LTXModel:
             b.w1, b.b1 = g(f"{pre}.ff.proj_in.weight"), g(f"{pre}.ff.proj_in.bias")
             b.w2, b.b2 = g(f"{pre}.ff.proj_out.weight"), g(f"{pre}.ff.proj_out.bias")
             tables.append(g(f"{pre}.scale_shift_table"))
-            for nm in ("to_q", "to_k"):     # the packed copies replace these
-                W.pop(f"{pre}.attn1.{nm}.weight", None)
             self.blocks.append(b)
         self.tables = torch.stack(tables, 0).contiguous()      # (L,6,D)
 
@@ -239,26 +249,46 @@ class LTXModel:
         return cls(config, W)
 
     # ------------------------------------------------------------------ forward
-    def _prepare_context(self, context: torch.Tensor) -> torch.Tensor:
+    def _prepare_context(self, context: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ltx.py:77-89: caption_projection, (B,S,3840) -> (B*S,D)."""
         b, s, c = context.shape
         h = ops.gemm(context.reshape(b * s, c), self.c1_w, self.c1_b, epilogue=ops.EPI_BIAS_GELU)
-        return ops.gemm(h, self.c2_w, self.c2_b)
+        return ops.gemm(h, self.c2_w, self.c2_b, out=out)
 
-    def _context_kv(self, blk: _Block, ctx: torch.Tensor, b: int, s: int, sp: int):
+    def _context_kv(self, blk: _Block, ctx: torch.Tensor, b: int, s: int, sp: int, out: Optional[tuple] = None):
         D, H, eps = self.inner_dim, self.num_attention_heads, self.config.norm_eps
-        k2 = ops.gemm(ctx, blk.wk2, blk.bk2)
+        if out is None:
+            k2 = torch.empty((b * s, D), dtype=BF16, device=ctx.device)
+            vt2 = torch.zeros((b, D, sp), dtype=BF16, device=ctx.device) if sp != s else \
+                torch.empty((b, D, sp), dtype=BF16, device=ctx.device)
+        else:
+            k2, vt2 = out
+        ops.gemm(ctx, blk.wk2, blk.bk2, out=k2)
         ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps)
-        vt2 = torch.zeros((b, D, sp), dtype=BF16, device=ctx.device) if sp != s else \
-            torch.empty((b, D, sp), dtype=BF16, device=ctx.device)
         ops.gemm(ctx, blk.wv2, blk.bv2, out=vt2, out_tokens_per_batch=s)
         return k2, vt2
 
+    def prepare_context(self, context: torch.Tensor, out: Optional[ContextKV] = None) -> ContextKV:
+        """Everything of the forward that depends on the text context only (3.37 TFLOP at S=1024, SURVEY.md
+        §8d).  The reference recomputes it in every forward; a denoise loop may hoist it (an algorithmic
+        change, always reported separately).  ``out``: refresh an existing object in place."""
+        context = context.to(BF16).contiguous()
+        b, s, _ = context.shape
+        sp = (s + 63) // 64 * 64
+        kv = out if out is not None else ContextKV(context.shape)
+        if kv.shape != tuple(context.shape):
+            raise ValueError(f"ContextKV was built for context {kv.shape}, got {tuple(context.shape)}")
+        kv.ctx = self._prepare_context(context, kv.ctx)
+        new = [self._context_kv(blk, kv.ctx, b, s, sp, kv.kv[i] if kv.kv else None) for i, blk in enumerate(self.blocks)]
+        kv.kv = new
+        return kv
+
     def forward_tokens(self, latent: torch.Tensor, plan: TimestepPlan, context: torch.Tensor,
-                       pe: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+                       pe: Tuple[torch.Tensor, torch.Tensor], ctx_kv: Optional[ContextKV] = None) -> torch.Tensor:
         """latent (B,N,128) bf16; context (B,S,3840) bf16; pe = (cos,sin) each (1|B,H,N,64) fp32
         (one table shared by every batch row, as in cfg_batch where it is a broadcast,
-        generate.py:1196-1202)."""
+        generate.py:1196-1202).  ``ctx_kv``: a ContextKV of THIS context (prepare_context); without it the
+        caption projection and the text K/V are recomputed here, as the reference does every forward."""
         cfg = self.config
         D, H, eps = self.inner_dim, self.num_attention_heads, cfg.norm_eps
         B, N, C = latent.shape
@@ -282,15 +312,12 @@ class LTXModel:
         mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D)  # (L,U,6,D)
         head = ops.ada_combine(self.head_table, emb.repeat(1, 2), 1, U, 2, D)[0]   # (U,2,D): shift, scale
 
-        ckey = context.data_ptr()
-        cached = self._ctx_cache.get(ckey) if self.cache_context else None
-        if cached is None:
-            ctx = self._prepare_context(context)
-            ctx_kv: List[Optional[tuple]] = [None] * cfg.num_layers
-            if self.cache_context:
-                self._ctx_cache = {ckey: (ctx, ctx_kv)}
+        if ctx_kv is not None:
+            if ctx_kv.shape != tuple(context.shape):
+                raise ValueError(f"ctx_kv was built for context {ctx_kv.shape}, got {tuple(context.shape)}")
+            ctx = ctx_kv.ctx
         else:
-            ctx, ctx_kv = cached
+            ctx = self._prepare_context(context)
 
         np64 = (N + 63) // 64 * 64
         sp64 = (S + 63) // 64 * 64
@@ -302,6 +329,10 @@ class LTXModel:
         q2 = torch.empty((M, D), dtype=BF16, device=dev)
         hff = torch.empty((M, 4 * D), dtype=BF16, device=dev)
         ms = 6 * D
+        kv_buf = None
+        if ctx_kv is None:                  # text K / V^T of the current block, recomputed every forward (one buffer pair)
+            kv_buf = (torch.empty((B * S, D), dtype=BF16, device=dev),
+                      torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev))
 
         for li, blk in enumerate(self.blocks):
             mod = mods[li]                                           # (U,6,D): shift,scale,gate x2
@@ -317,11 +348,7 @@ class LTXModel:
             ops.rmsnorm_modulate(x, eps, out=nx)
             ops.gemm(nx, blk.wq2, blk.bq2, out=q2)
             ops.qknorm_rope(q2, 1, D, blk.wqn2, None, None, N, H, eps)
-            kv = ctx_kv[li]
-            if kv is None:
-                kv = self._context_kv(blk, ctx, B, S, sp64)
-                if self.cache_context:
-                    ctx_kv[li] = kv
+            kv = ctx_kv.kv[li] if ctx_kv is not None else self._context_kv(blk, ctx, B, S, sp64, kv_buf)
             ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale)
             ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x)
             # feed-forward (transformer.py:343-347)

@@ -57,6 +57,22 @@ def load_frames(source: Union[str, Path, np.ndarray], height: int, width: int, f
     return arr.astype(np.float32)
 
 
+def resize_conditioning(frames01: np.ndarray, height: int, width: int, is_video: bool) -> torch.Tensor:
+    """(F,H,W,3) in [0,1] -> (1,3,F,height,width) in [-1,1], resized the way the reference prepares an already
+    decoded source of another size: images through uint8 + LANCZOS (prepare_image_for_encoding, utils.py:643-661:
+    `(image*255).astype(uint8)`, i.e. truncation), video frames with an area filter (prepare_video_for_encoding,
+    utils.py:699-705; cv2.INTER_AREA there, PIL's BOX filter here - cv2 is not installed in this image)."""
+    from PIL import Image
+    out = []
+    for f in frames01:
+        u8 = (f * 255).astype(np.uint8)
+        flt = Image.Resampling.BOX if is_video else Image.Resampling.LANCZOS
+        out.append(np.asarray(Image.fromarray(u8).resize((width, height), flt)).astype(np.float32) / 255.0)
+    arr = np.stack(out, 0)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).permute(3, 0, 1, 2)[None]
+    return t * 2.0 - 1.0
+
+
 def frames_to_conditioning(frames: np.ndarray) -> torch.Tensor:
     """(F,H,W,3) in [0,1] -> (1,3,F,H,W) in [-1,1]; F is trimmed to 1+8k as the encoder requires
     (video_vae.py:332-337)."""

@@ -195,9 +195,11 @@ def latent_to_tokens(latent: torch.Tensor, rep: int = 1) -> torch.Tensor:
 def cfg_euler_step(v_pos: torch.Tensor, v_neg: Optional[torch.Tensor], latent: torch.Tensor, cfg_scale: float,
                    sigma: float, sigma_next: float, clean: Optional[torch.Tensor] = None,
                    mask_tok: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                   sigmas_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   sigmas_dev: Optional[torch.Tensor] = None, bf16_euler: bool = False) -> torch.Tensor:
     """v_* (B,S,C) tokens; latent (B,C,...) channels-first; mask_tok (B,S) float32.  With ``sigmas_dev`` (2
-    float32 on the device) the scalars are read from device memory (hipGraph replay)."""
+    float32 on the device) the scalars are read from device memory (hipGraph replay).  ``out`` may be
+    ``latent`` itself (each element is read and written by one thread).  ``bf16_euler``: the reference's
+    fp32_euler=False compiled step (generate.py:741-748)."""
     _req(latent, BF16, "cfg_euler_step.latent")
     B, C = latent.shape[:2]
     S = latent.numel() // (B * C)
@@ -205,11 +207,22 @@ def cfg_euler_step(v_pos: torch.Tensor, v_neg: Optional[torch.Tensor], latent: t
         out = torch.empty_like(latent)
     if sigmas_dev is not None:
         check(_lib.load().ltxk_cfg_euler_step_dev(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
-                                                  B, C, S, cfg_scale, _p(sigmas_dev), _stream()), "ltxk_cfg_euler_step_dev")
+                                                  B, C, S, cfg_scale, _p(sigmas_dev), int(bf16_euler), _stream()),
+              "ltxk_cfg_euler_step_dev")
         return out
     check(_lib.load().ltxk_cfg_euler_step(_p(v_pos), _p(v_neg), _p(latent), _p(out), _p(clean), _p(mask_tok),
-                                          B, C, S, cfg_scale, sigma, sigma_next, _stream()), "ltxk_cfg_euler_step")
+                                          B, C, S, cfg_scale, sigma, sigma_next, int(bf16_euler), _stream()),
+          "ltxk_cfg_euler_step")
     return out
+
+
+def step_scalars(ts_all: torch.Tensor, sig_all: torch.Tensor, step: torch.Tensor, ts: torch.Tensor, sig: torch.Tensor) -> None:
+    """ts_all (steps,U) bf16, sig_all (steps,2) fp32, step (1) int32 -> ts (U), sig (2); step += 1 (device side)."""
+    _req(ts_all, BF16, "step_scalars.ts_all")
+    n, U = ts_all.shape
+    if sig_all.dtype != torch.float32 or tuple(sig_all.shape) != (n, 2) or step.dtype != torch.int32 or ts.numel() != U:
+        raise TypeError("step_scalars: bad table shapes / dtypes")
+    check(_lib.load().ltxk_step_scalars(_p(ts_all), _p(sig_all), _p(step), _p(ts), _p(sig), U, n, _stream()), "ltxk_step_scalars")
 
 
 def euler_only(latent: torch.Tensor, denoised: torch.Tensor, sigma: float, sigma_next: float) -> torch.Tensor:

@@ -2,8 +2,7 @@
 residual stack, per-frame Conv2d + PixelShuffle(2), and the un-normalise / re-normalise wrapper
 (upsampler.py:297-316).  Needed between the two stages of the distilled / keyframe / ic_lora pipelines
 (generate.py:3196).  Convolutions reuse the VAE's implicit-GEMM kernel with zero temporal padding
-(``causal=2``); the per-frame 3x3 Conv2d runs as that kernel with frames as the batch axis, depth 1 and
-the 2-D kernel embedded in the middle temporal slice."""
+(``causal=2``); the per-frame 3x3 Conv2d runs as that kernel's 9-tap mode (``taps_d=1``: K = 9*Cin, only the centre temporal tap)."""
 from __future__ import annotations
 
 from typing import Dict
@@ -37,10 +36,6 @@ class LatentUpsampler:
             raise ValueError("Missing latent-upsampler parameters (initial_conv / upsampler.conv)")
         self.mid_channels = W["initial_conv.weight"].shape[0]       # detected from the weights (upsampler.py:333-337)
         self.nb = num_blocks_per_stage
-        w2 = W["upsampler.conv.weight"]                              # (4*mid,3,3,mid)
-        w3 = torch.zeros((w2.shape[0], 3, 3, 3, w2.shape[-1]), dtype=BF16, device=w2.device)
-        w3[:, 1] = w2
-        W["upsampler.conv.weight3d"] = w3
         self.W = W
 
     def _res(self, x: torch.Tensor, pre: str) -> torch.Tensor:
@@ -59,7 +54,8 @@ class LatentUpsampler:
         for i in range(self.nb):
             x = self._res(x, f"res_blocks.{i}")
         B, D, H, Wd, C = x.shape
-        y = conv3d(x.reshape(B * D, 1, H, Wd, C), W["upsampler.conv.weight3d"], W["upsampler.conv.bias"], ZERO_T, PAD_ZEROS)
+        # per-frame 3x3 Conv2d (upsampler.py:64-99): the conv kernel's 9-tap mode (no zero-filled temporal taps)
+        y = conv3d(x, W["upsampler.conv.weight"], W["upsampler.conv.bias"], ZERO_T, PAD_ZEROS)
         # PixelShuffle(2) (upsampler.py:101-122): channel (oc, ry, rx) -> pixel (2h+ry, 2w+rx); pure index map
         y = y.reshape(B * D, H, Wd, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B, D, 2 * H, 2 * Wd, C).contiguous()
         for i in range(self.nb):

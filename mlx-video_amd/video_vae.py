@@ -58,19 +58,24 @@ def _zero_page(dev) -> torch.Tensor:
 # ------------------------------------------------------------------------------------ op shims
 def conv3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, causal: bool, pad_mode: int,
            resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x (B,D,H,W,Cin) bf16 channels-last; w (Cout,3,3,3,Cin); returns (B,D,H,W,Cout)."""
+    """x (B,D,H,W,Cin) bf16 channels-last; w (Cout,3,3,3,Cin), or (Cout,3,3,Cin) for a per-frame 3x3 kernel;
+    returns (B,D,H,W,Cout)."""
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
+    taps_d = 3 if w.dim() == 5 else 1
+    if tuple(w.shape[1:]) != ((3, 3, 3, Cin) if taps_d == 3 else (3, 3, Cin)):
+        raise ValueError(f"conv3d: weight {tuple(w.shape)} does not match Cin={Cin}")
     out = torch.empty((B, D, H, W, Cout), dtype=BF16, device=x.device)
     a = Conv3dArgs()
     a.x, a.w, a.bias, a.out, a.resid = _p(x), _p(w), _p(b), _p(out), _p(resid)
     a.zero_page = _p(_zero_page(x.device))
     a.B, a.D, a.H, a.W, a.Cin, a.Cout = B, D, H, W, Cin, Cout
-    a.causal, a.pad_mode = int(causal), pad_mode
+    a.causal, a.pad_mode, a.taps_d = int(causal), pad_mode, taps_d
     ws = _workspace(x.device)
     a.workspace, a.workspace_bytes = _p(ws), ws.numel() * 4
     V = B * D * H * W
-    with ops._timed("conv3d_k3", 2.0 * 27 * Cin * Cout * V, 2.0 * V * (Cin + Cout) + 2.0 * 27 * Cin * Cout):
+    ntap = 27 if taps_d == 3 else 9
+    with ops._timed("conv3d_k3", 2.0 * ntap * Cin * Cout * V, 2.0 * V * (Cin + Cout) + 2.0 * ntap * Cin * Cout):
         check(_lib.load().ltxk_conv3d_k3_bf16(ctypes.byref(a), _stream()), "ltxk_conv3d_k3_bf16")
     return out
 
@@ -236,8 +241,10 @@ def map_spatial_slice(begin, end, left_ramp, right_ramp, scale):
 
 def decode_with_tiling(decoder_fn, latents: torch.Tensor, tiling_config: TilingConfig, spatial_scale: int = 32,
                        temporal_scale: int = 8, causal: bool = False, timestep=None, chunked_conv: bool = False,
-                       on_frames_ready: Optional[Callable] = None) -> torch.Tensor:
-    """tiling.py:279-509: decode t/h/w tiles, fp32 accumulate tile*mask and mask, divide."""
+                       on_frames_ready: Optional[Callable] = None, noise_fn: Optional[Callable] = None) -> torch.Tensor:
+    """tiling.py:279-509: decode t/h/w tiles, fp32 accumulate tile*mask and mask, divide.  ``noise_fn(shape)``: the
+    noise source of a timestep-conditioned decoder, called once per tile with the tile's latent shape (the reference
+    draws mx.random.normal inside every decoder call, decoder.py:381-385)."""
     b, c, fl, hl, wl = latents.shape
     out_f, out_h, out_w = 1 + (fl - 1) * temporal_scale, hl * spatial_scale, wl * spatial_scale
     sc, tc = tiling_config.spatial_config, tiling_config.temporal_config
@@ -267,7 +274,8 @@ def decode_with_tiling(decoder_fn, latents: torch.Tensor, tiling_config: TilingC
             for wi in range(len(wiv.starts)):
                 wsl, wmask = map_spatial_slice(wiv.starts[wi], wiv.ends[wi], wiv.left_ramps[wi], wiv.right_ramps[wi], spatial_scale)
                 tile_lat = latents[:, :, tiv.starts[ti]:tiv.ends[ti], hiv.starts[hi_]:hiv.ends[hi_], wiv.starts[wi]:wiv.ends[wi]].contiguous()
-                tile = decoder_fn(tile_lat, causal=causal, timestep=timestep, debug=False, chunked_conv=chunked_conv)
+                kw = {"noise_fn": noise_fn} if noise_fn is not None else {}
+                tile = decoder_fn(tile_lat, causal=causal, timestep=timestep, debug=False, chunked_conv=chunked_conv, **kw)
                 _, _, dt_, dh_, dw_ = tile.shape
                 at, ah, aw = min(dt_, tsl.stop - tsl.start), min(dh_, hsl.stop - hsl.start), min(dw_, wsl.stop - wsl.start)
                 mt, mh, mw = tmask[:at].to(dev), hmask[:ah].to(dev), wmask[:aw].to(dev)
@@ -334,10 +342,12 @@ class LTX2VideoDecoder:
         return ops.gemm(h, W[f"{prefix}.timestep_embedder.linear_2.weight"], W[f"{prefix}.timestep_embedder.linear_2.bias"])
 
     def __call__(self, sample: torch.Tensor, causal: bool = False, timestep: Optional[torch.Tensor] = None,
-                 debug: bool = False, chunked_conv: bool = False, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 debug: bool = False, chunked_conv: bool = False, noise: Optional[torch.Tensor] = None,
+                 noise_fn: Optional[Callable] = None) -> torch.Tensor:
         """(B,128,F',H',W') -> (B,3,8(F'-1)+1,32H',32W') bf16.  ``chunked_conv`` is accepted for
         interface parity; the temporal chunking of convolution.py:168-222 / sampling.py:199-275 is
-        an MLX memory workaround whose result equals the unchunked op."""
+        an MLX memory workaround whose result equals the unchunked op.  A timestep-conditioned decoder needs
+        ``noise`` (this call's tensor) or ``noise_fn(shape)`` (drawn here, as the reference does per call)."""
         W = self.W
         if sample.dim() != 5 or sample.shape[1] != 128:
             raise ValueError(f"latents must be (B,128,F,H,W), got {tuple(sample.shape)}")
@@ -346,9 +356,12 @@ class LTX2VideoDecoder:
         tc = self.timestep_conditioning
         st = None
         if tc:
+            if noise is None and noise_fn is not None:
+                noise = noise_fn(tuple(sample.shape))
             if noise is None:
                 raise ValueError("timestep-conditioned decode needs an explicit `noise` tensor (the reference draws "
-                                 "mx.random.normal, decoder.py:381-385; MLX's stream is not reproducible here)")
+                                 "mx.random.normal, decoder.py:381-385; MLX's stream is not reproducible here): "
+                                 "pass noise= or noise_fn=")
             nz = noise.to(BF16).contiguous()
             tval = self.decode_timestep if timestep is None else float(timestep.reshape(-1)[0])
             st = torch.full((B,), tval * 1000.0, dtype=torch.float32, device=x.device).to(BF16)
@@ -392,8 +405,8 @@ class LTX2VideoDecoder:
 
     def decode_tiled(self, sample: torch.Tensor, tiling_config: Optional[TilingConfig] = None, tiling_mode: str = "auto",
                      causal: bool = False, timestep=None, debug: bool = False,
-                     on_frames_ready: Optional[Callable] = None) -> torch.Tensor:
-        """decoder.py:452-531."""
+                     on_frames_ready: Optional[Callable] = None, noise_fn: Optional[Callable] = None) -> torch.Tensor:
+        """decoder.py:452-531.  ``noise_fn``: see decode_with_tiling."""
         if tiling_config is None:
             tiling_config = TilingConfig.default()
         _, _, f, h, w = sample.shape
@@ -404,14 +417,14 @@ class LTX2VideoDecoder:
         if tiling_config.temporal_config is not None:
             need_t = f > tiling_config.temporal_config.tile_size_in_frames // 8
         if not need_s and not need_t:
-            out = self(sample, causal=causal, timestep=timestep)
+            out = self(sample, causal=causal, timestep=timestep, noise_fn=noise_fn)
             if on_frames_ready is not None:
                 try:
                     on_frames_ready(out, 0)
                 except Exception:        # the reference swallows callback errors here (decoder.py:514-518)
                     pass
             return out
-        return decode_with_tiling(self, sample, tiling_config, 32, 8, causal, timestep, False, on_frames_ready)
+        return decode_with_tiling(self, sample, tiling_config, 32, 8, causal, timestep, False, on_frames_ready, noise_fn)
 
 
 def to_uint8_frames(video: torch.Tensor) -> torch.Tensor:
@@ -515,6 +528,33 @@ def random_decoder_weights(dev, seed: int = 1234, timestep_conditioning: bool = 
         else:
             conv(f"up_blocks.{bi}.conv", c * 4, c)
     conv("conv_out.conv", 48, 128)
+    return W
+
+
+def random_encoder_weights(dev, seed: int = 4321, blocks=None) -> Dict[str, torch.Tensor]:
+    """Random weights of the encoder architecture (encoder.py:95-105), generated on the device (synthetic runs)."""
+    blocks = ENC_BLOCKS if blocks is None else blocks
+    g = torch.Generator(device=dev).manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+
+    def conv(name, o, i):
+        W[f"{name}.weight"] = (torch.randn((o, 3, 3, 3, i), generator=g, device=dev) / math.sqrt(27 * i)).to(BF16)
+        W[f"{name}.bias"] = (torch.randn((o,), generator=g, device=dev) * 0.01).to(BF16)
+
+    conv("conv_in", 128, 48)
+    ch = 128
+    for bi, (kind, arg) in enumerate(blocks):
+        pre = f"down_blocks.{bi}"
+        if kind == "res_x":
+            for li in range(arg):
+                conv(f"{pre}.res_blocks.{li}.conv1", ch, ch)
+                conv(f"{pre}.res_blocks.{li}.conv2", ch, ch)
+        else:
+            conv(f"{pre}.conv", ch * 2 // (arg[0] * arg[1] * arg[2]), ch)
+            ch *= 2
+    conv("conv_out", 129, ch)
+    W["per_channel_statistics.mean"] = torch.zeros(128, dtype=BF16, device=dev)
+    W["per_channel_statistics.std"] = torch.ones(128, dtype=BF16, device=dev)
     return W
 
 
