@@ -342,11 +342,12 @@ def bf16_round_scalar(x: float) -> float:
 def denoise_dev(latents: Tensor, positions: np.ndarray, ctx_pos: Tensor, ctx_neg: Tensor,
                 W: Dict[str, Tensor], cfg: DiTConfig, sigmas: Sequence[float], p: Prec,
                 cfg_scale: float = 4.0, clean_latent: Optional[Tensor] = None,
-                denoise_mask: Optional[Tensor] = None, compiled: bool = True) -> Tensor:
+                denoise_mask: Optional[Tensor] = None, compiled: bool = True, bf16_euler: bool = False) -> Tensor:
     """denoise_dev loop (generate.py:1060-1327).  ``compiled=True`` follows the mx.compile'd
     step (bf16-rounded sigma in x0 and Euler, generate.py:1109-1174); ``False`` follows the
     eager body (Python-float sigma in Euler, 1293-1301).  Timesteps are sigma_bf16*mask in
-    both (1084,1237)."""
+    both (1084,1237).  ``cfg_scale == 1`` is the distilled (no-CFG) loop, generate.py:564-881, whose compiled
+    step with ``bf16_euler`` (fp32_euler=False) evaluates the Euler update op by op in bf16 (generate.py:748)."""
     b, c, f, h, w = latents.shape
     n = f * h * w
     pe = precompute_freqs_cis(torch.from_numpy(positions), cfg.dim, cfg.theta, cfg.max_pos, cfg.heads)
@@ -370,7 +371,9 @@ def denoise_dev(latents: Tensor, positions: np.ndarray, ctx_pos: Tensor, ctx_neg
         x0 = to_denoised(x, vel, s_m, p)
         if denoise_mask is not None:
             x0 = apply_denoise_mask(x0, p.r(clean_latent), p.r(denoise_mask), p)
-        if compiled:
+        if compiled and bf16_euler:
+            x = p.r(x0 + p.r(p.r(sn_m * p.r(x - x0)) / s_m))
+        elif compiled:
             x = p.r(x0 + sn_m * (x - x0) / s_m)
         else:
             x = euler_step(x, x0, s, s_next, p)

@@ -1,0 +1,302 @@
+"""Oracle parity at the sizes of BASELINE.json configs 3, 4 and 5 (VERDICT r01 "configs_untested"):
+
+  config 3  distilled two-stage 768x768x65 + 2x upscaler : N=1296 -> N=5184 tokens, latent 9x12x12 -> 9x24x24,
+            spatially tiled decode of 768x768 (384 px tiles, 64 px overlap)
+  config 4  dev 512x512x97                               : N=3328 tokens, temporally tiled decode (64 f tiles, 24 f overlap)
+  config 5  ic_lora 768x768x65 with merged LoRA          : config 3's sizes + a 65-frame video conditioning through the
+            default 9-block encoder + LoRA merge at 4096x4096
+
+Full-width (D=4096) single blocks are compared at the real token counts; the end-to-end pipelines run a narrow
+(D=512) 2-block model at the REAL latent geometry against the oracle composed end to end (oracle/pipeline.py) with
+the same injected noise.  Measured errors go to the parity ledger (tests/parity.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from oracle import dit as O
+from oracle import pipeline as OP
+from oracle import sched as S
+from oracle import vae as OV
+from parity import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+# ---------------------------------------------------------------------------------------------------- (a) full-width blocks
+@pytest.mark.parametrize("name,F,Hh,Ww,bound", [("N5184_768x768x65", 9, 24, 24, 8e-3), ("N3328_512x512x97", 13, 16, 16, 8e-3)])
+def test_block_fullwidth_at_config_sizes(dev, name, F, Hh, Ww, bound):
+    """One full-width DiT block (D=4096, 32 heads, FF 16384, S=1024) at N=5184 (config 3/5 stage 2) and N=3328
+    (config 4), B=1, vs oracle.ltx_forward in the bf16 policy."""
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig, Modality
+    cfg = O.DiTConfig(num_layers=1)
+    W = O.make_weights(cfg, seed=12)
+    model = LTXModel(LTXModelConfig(num_layers=1), {k: v.to(dev) for k, v in W.items()})
+    N, S_ = F * Hh * Ww, 1024
+    g = torch.Generator().manual_seed(44)
+    lat = torch.randn(1, N, 128, generator=g).to(BF)
+    ctx = torch.randn(1, S_, 3840, generator=g).to(BF)
+    ts = torch.full((1, N), 0.725).to(BF)
+    pos = torch.from_numpy(O.create_position_grid(1, F, Hh, Ww))
+    pe = O.precompute_freqs_cis(pos, cfg.dim)
+    v, _ = model(video=Modality(latent=lat.to(dev), timesteps=ts.to(dev), positions=pos.to(dev), context=ctx.to(dev)))
+    torch.cuda.synchronize()
+    ref = O.ltx_forward(lat.float(), ts.float(), ctx.float(), pe, W, cfg, O.BF16)
+    assert v.shape == (1, N, 128)
+    parity.check(f"dit.fullwidth_block_{name}.velocity_vs_bf16_oracle", rel_l2(v.float(), ref), bound)
+
+
+# ---------------------------------------------------------------------------------------------------- (b) two-stage pipelines
+def _narrow(dev, seed=61):
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+    cfg = O.DiTConfig(num_layers=2, heads=4, caption_channels=256)
+    W = O.make_weights(cfg, seed=seed)
+    mc = LTXModelConfig(num_attention_heads=4, num_layers=2, caption_channels=256, cross_attention_dim=cfg.dim)
+    Wdev = {k: v.to(dev) for k, v in W.items()}
+    return cfg, W, mc, Wdev
+
+
+class _Noise:
+    """Deterministic noise source shared by the product run and the oracle run (draws are logged in call order)."""
+
+    def __init__(self, seed, dev):
+        self.g = torch.Generator().manual_seed(seed)
+        self.dev = dev
+        self.log = []
+
+    def __call__(self, shape):
+        n = torch.randn(shape, generator=self.g).to(BF)
+        self.log.append(n)
+        return n.to(self.dev)
+
+
+class _Replay:
+    def __init__(self, log):
+        self.log, self.i = log, 0
+
+    def __call__(self, shape):
+        n = self.log[self.i]
+        self.i += 1
+        assert tuple(n.shape) == tuple(shape)
+        return n
+
+
+def _lora_files(tmp_path, W, cfg, seed, rank=8, keys=None, name="lora.safetensors"):
+    """A rank-`rank` LoRA over the attention / FF projections in the PyTorch LTX-2 key naming (lora.py:18-33)."""
+    from safetensors.torch import save_file
+    g = torch.Generator().manual_seed(seed)
+    sd, pairs = {}, {}
+    for i in range(cfg.num_layers):
+        for mod, raw in (("attn1.to_q", "attn1.to_q"), ("attn1.to_k", "attn1.to_k"), ("attn1.to_v", "attn1.to_v"),
+                         ("attn1.to_out", "attn1.to_out.0"), ("attn2.to_q", "attn2.to_q"), ("ff.proj_in", "ff.net.0.proj"),
+                         ("ff.proj_out", "ff.net.2")):
+            key = f"transformer_blocks.{i}.{mod}.weight"
+            if keys is not None and mod not in keys:
+                continue
+            o, n_in = W[key].shape
+            A = (torch.randn(rank, n_in, generator=g) * 0.05).to(BF)
+            B = (torch.randn(o, rank, generator=g) * 0.05).to(BF)
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_A.weight"] = A
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_B.weight"] = B
+            pairs[key] = (A.float(), B.float())
+    path = tmp_path / name
+    save_file(sd, str(path))
+    return path, pairs
+
+
+@pytest.mark.parametrize("pipe", ["distilled_i2v_stage2lora", "ic_lora"])
+def test_two_stage_pipelines_match_oracle_at_768x768x65(dev, tmp_path, pipe):
+    """generate.py:3050-3372 at config 3 / 5 geometry: 768x768x65 -> stage 1 latent 9x12x12 (N=1296), stage 2 latent
+    9x24x24 (N=5184), 8 + 3 steps, narrow 2-block DiT, reduced-depth VAE encoder / upsampler; final LATENTS vs the
+    oracle pipeline with the same noise.  distilled: one image conditioning (replace, frame 0) at both stages + a
+    distilled LoRA merged into the stage-2 transformer only.  ic_lora: merged LoRA on both stages + a 65-frame video
+    conditioning (stage 1 keyframe guide) + an image."""
+    from mlx_video_amd.generate import PipelineType, generate_video
+    from mlx_video_amd.schedulers import STAGE_1_SIGMAS, STAGE_2_SIGMAS, _subsample_refinement_sigmas, _subsample_sigmas
+    from mlx_video_amd.upsampler import LatentUpsampler
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, VideoEncoder
+    cfg, W, mc, Wdev = _narrow(dev)
+    blocks = [("res_x", 1), ("compress_space_res", (1, 2, 2)), ("res_x", 1), ("compress_time_res", (2, 1, 1)),
+              ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1), ("compress_all_res", (2, 2, 2)), ("res_x", 1)]
+    We = OV.make_encoder_weights(seed=63, blocks=blocks)
+    Wu = OV.make_upsampler_weights(mid=128, nb=1)
+    Wd = OV.make_decoder_weights(seed=62, layers_per_block=1)
+    enc = VideoEncoder({k: v.to(dev) for k, v in We.items()}, encoder_blocks=blocks)
+    ups = LatentUpsampler({k: v.to(dev) for k, v in Wu.items()}, num_blocks_per_stage=1)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in Wd.items()}, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(70)
+    emb = torch.randn(1, 64, 256, generator=g).to(BF)
+    H = Wd_ = 768
+    F = 65
+    img = (torch.rand(1, 3, 1, H, Wd_, generator=g) * 2 - 1)
+    lora_path, pairs = _lora_files(tmp_path, W, cfg, seed=71)
+    noise = _Noise(9, dev)
+    kw = dict(prompt="x", height=H, width=Wd_, num_frames=F, stage1_steps=8, stage2_steps=3, vae_decoder=dec, vae_encoder=enc,
+              upsampler=ups, prompt_embeds=emb, noise_fn=noise, device=dev, return_latents=True, transformer_weights=Wdev,
+              transformer_config=mc)
+    p = O.BF16
+    sig1 = _subsample_sigmas(list(STAGE_1_SIGMAS), 8, "farthest")
+    sig2 = _subsample_refinement_sigmas(list(STAGE_2_SIGMAS), 3, "farthest")
+    from mlx_video_amd.generate import _cond_pixels
+    img_h = _cond_pixels(img, H // 2, Wd_ // 2, False, F)            # host-side resize, shared by both runs (utils.py:643-661)
+    z1 = OV.vae_encode(p.r(img_h.float()), We, p, blocks)
+    z2 = OV.vae_encode(p.r(img.float()), We, p, blocks)
+    Wm = OP.merge_lora(W, pairs, 0.8, p)
+    if pipe == "ic_lora":
+        vid = (torch.rand(1, 3, F, H // 2, Wd_ // 2, generator=g) * 2 - 1)    # already at the stage-1 resolution
+        lat = generate_video(pipeline=PipelineType.IC_LORA, images=[(img, 0, 1.0)], video_conditionings=[(vid, 0, 0.9)],
+                             loras=[(str(lora_path), 0.8)], **kw)
+        zv = OV.vae_encode(p.r(vid.float()), We, p, blocks)
+        conds1 = [("replace", z1, 0, 1.0), ("guide", zv, 0, 0.9)]       # images first, then the video guide (generate.py:3155)
+        conds2 = [("replace", z2, 0, 1.0)]
+        W1, W2 = Wm, Wm
+    else:
+        lat = generate_video(pipeline=PipelineType.DISTILLED, images=[(img, 0, 1.0)], distilled_loras=[(str(lora_path), 0.8)], **kw)
+        conds1, conds2 = [("replace", z1, 0, 1.0)], [("replace", z2, 0, 1.0)]
+        W1, W2 = W, Wm
+    torch.cuda.synchronize()
+    assert lat.shape == (1, 128, 9, 24, 24)
+    r1, r2 = OP.two_stage(_Replay(noise.log), emb.float(), W1, W2, cfg, Wu, 1, Wd["latents_mean"], Wd["latents_std"], 9,
+                          (12, 12), (24, 24), sig1, sig2, conds1, conds2, p, compiled=False)
+    parity.check(f"pipeline.{pipe}_768x768x65.final_latents_vs_oracle", rel_l2(lat.float(), r2), 2.5e-2)
+    if pipe != "ic_lora":
+        # the stage-2 LoRA must matter: the same run without it lands measurably elsewhere
+        noise2 = _Noise(9, dev)
+        kw2 = dict(kw, noise_fn=noise2)
+        lat0 = generate_video(pipeline=PipelineType.DISTILLED, images=[(img, 0, 1.0)], **kw2)
+        assert rel_l2(lat0.float(), lat.float()) > 5 * rel_l2(lat.float(), r2)
+
+
+def test_loras_need_reachable_base_weights(dev):
+    from mlx_video_amd.generate import PipelineType, generate_video
+    from mlx_video_amd.ltx_model import LTXModel
+    from mlx_video_amd.video_vae import LTX2VideoDecoder
+    cfg, W, mc, Wdev = _narrow(dev)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in OV.make_decoder_weights(seed=62, layers_per_block=1).items()}, num_layers_per_block=1)
+    emb = torch.zeros(1, 64, 256, dtype=BF)
+    with pytest.raises(ValueError, match="base transformer weights are not reachable"):
+        generate_video(pipeline=PipelineType.DEV, transformer=LTXModel(mc, Wdev), vae_decoder=dec, prompt_embeds=emb,
+                       loras=[("nowhere.safetensors", 1.0)], device=dev)
+    # two models from ONE dict (the stage-2 / LoRA case): construction must not consume the caller's weights
+    n0 = len(Wdev)
+    LTXModel(mc, Wdev)
+    LTXModel(mc, Wdev)
+    assert len(Wdev) == n0
+
+
+# ---------------------------------------------------------------------------------------------------- (c) tiled decodes
+def test_temporal_tiled_decode_97_frames_vs_oracle(dev):
+    """Config 4's decode policy: TilingConfig.auto(512,512,97) = temporal tiles of 64 frames, 24 overlap, no spatial
+    tiling (tiling.py:152-211).  97 frames = 13 latent frames, on a 2x2 latent (64x64 px), layers_per_block=1."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig
+    tc = TilingConfig.auto(512, 512, 97)
+    assert tc.spatial_config is None and (tc.temporal_config.tile_size_in_frames, tc.temporal_config.tile_overlap_in_frames) == (64, 24)
+    W = OV.make_decoder_weights(seed=5, layers_per_block=1)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(8)
+    lat = torch.randn(1, 128, 13, 2, 2, generator=g).to(BF)
+    chunks = []
+    out = dec.decode_tiled(lat.to(dev), tiling_config=tc, tiling_mode="temporal", on_frames_ready=lambda fr, s: chunks.append((s, fr.shape[2])))
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 97, 64, 64)
+    assert sum(n for _, n in chunks) == 97 and [s for s, _ in chunks] == sorted(s for s, _ in chunks)    # streamed in order, no gap
+    ref = OV.decode_with_tiling(lambda z: OV.vae_decode(z, W, O.BF16, layers_per_block=1), lat.float(), None, 0, 64, 24, O.BF16)
+    parity.check("vae.temporal_tiled_decode_97f.video_vs_oracle_tiling", rel_l2(out.float(), ref), 1.6e-2)
+
+
+def test_spatial_tiled_decode_768_vs_oracle(dev):
+    """Config 3/5's decode policy: TilingConfig.auto(768,768,65) = 384 px tiles, 64 px overlap, no temporal tiling.
+    Latent 24x24 (768x768 px, 3x3 tiles) with ONE latent frame (the tile geometry is what is under test)."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig
+    tc = TilingConfig.auto(768, 768, 65)
+    assert tc.temporal_config is None and (tc.spatial_config.tile_size_in_pixels, tc.spatial_config.tile_overlap_in_pixels) == (384, 64)
+    W = OV.make_decoder_weights(seed=6, layers_per_block=1)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(9)
+    lat = torch.randn(1, 128, 1, 24, 24, generator=g).to(BF)
+    out = dec.decode_tiled(lat.to(dev), tiling_config=tc, tiling_mode="spatial")
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 1, 768, 768)
+    ref = OV.decode_with_tiling(lambda z: OV.vae_decode(z, W, O.BF16, layers_per_block=1), lat.float(), 384, 64, None, 0, O.BF16)
+    parity.check("vae.spatial_tiled_decode_768.video_vs_oracle_tiling", rel_l2(out.float(), ref), 1.6e-2)
+
+
+def test_tiled_decode_timestep_conditioned_vs_oracle(dev):
+    """A timestep-conditioned decoder decoded TILED: fresh noise per tile through noise_fn (decoder.py:381-385), same
+    draws replayed into the oracle's tiling."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig
+    W = OV.make_decoder_weights(seed=7, layers_per_block=1, timestep_conditioning=True)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, timestep_conditioning=True, num_layers_per_block=1)
+    g = torch.Generator().manual_seed(10)
+    lat = torch.randn(1, 128, 2, 4, 4, generator=g).to(BF)
+    noise = _Noise(11, dev)
+    out = dec.decode_tiled(lat.to(dev), tiling_config=TilingConfig.spatial_only(64, 32), tiling_mode="spatial", noise_fn=noise)
+    torch.cuda.synchronize()
+    assert len(noise.log) == 9 and out.shape == (1, 3, 9, 128, 128)       # 3x3 tiles, one draw each
+    rp = _Replay(noise.log)
+    ref = OV.decode_with_tiling(lambda z: OV.vae_decode(z, W, O.BF16, layers_per_block=1, timestep=0.05,
+                                                        noise=rp(tuple(z.shape)).float()), lat.float(), 64, 32, None, 0, O.BF16)
+    parity.check("vae.tiled_decode_timestep_conditioned.video_vs_oracle_tiling", rel_l2(out.float(), ref), 1.6e-2)
+    with pytest.raises(ValueError, match="noise"):
+        dec.decode_tiled(lat.to(dev), tiling_config=TilingConfig.spatial_only(64, 32), tiling_mode="spatial")
+
+
+def test_tiled_decode_fullsize_properties(dev):
+    """Config 3/4 decodes at their full sizes (65x768x768 spatial tiles; 97x512x512 temporal tiles), default depth.
+    Size-independent properties: shape / finiteness; wherever exactly one tile contributes with weight 1 the blended
+    output equals that tile's own decode bit for bit."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig, random_decoder_weights
+    dec = LTX2VideoDecoder(random_decoder_weights(dev))
+    g = torch.Generator(device=dev).manual_seed(12)
+    lat = torch.randn((1, 128, 9, 24, 24), generator=g, device=dev).to(BF)
+    out = dec.decode_tiled(lat, tiling_config=TilingConfig.auto(768, 768, 65), tiling_mode="auto")
+    assert out.shape == (1, 3, 65, 768, 768) and bool(torch.isfinite(out.float()).all())
+    t00 = dec(lat[:, :, :, :12, :12].contiguous())                       # tile (0,0): latent rows/cols 0..11 = px 0..383
+    assert torch.equal(out[:, :, :, :320, :320], t00[:, :, :, :320, :320])   # px < 320 lie outside every overlap ramp
+    del out, t00
+    lat = torch.randn((1, 128, 13, 16, 16), generator=g, device=dev).to(BF)
+    out = dec.decode_tiled(lat, tiling_config=TilingConfig.auto(512, 512, 97), tiling_mode="auto")
+    assert out.shape == (1, 3, 97, 512, 512) and bool(torch.isfinite(out.float()).all())
+    t0 = dec(lat[:, :, :8].contiguous())                                  # temporal tile 0: latent frames 0..7 = frames 0..56
+    assert torch.equal(out[:, :, :33], t0[:, :, :33])                      # tile 1 starts at latent frame 4 (frame 25+8): ramp begins later
+
+
+# ---------------------------------------------------------------------------------------------------- (d) default encoder
+def test_default_encoder_blocks_vs_oracle(dev):
+    """The DEFAULT 9-block encoder (4-6-6-2-2 res blocks, encoder.py:95-105) on a 9x64x64 clip."""
+    from mlx_video_amd.video_vae import ENC_BLOCKS, VideoEncoder
+    assert ENC_BLOCKS == OV.ENC_BLOCKS
+    W = OV.make_encoder_weights(seed=21)
+    enc = VideoEncoder({k: v.to(dev) for k, v in W.items()})
+    g = torch.Generator().manual_seed(22)
+    vid = (torch.rand(1, 3, 9, 64, 64, generator=g) * 2 - 1).to(BF)
+    z = enc(vid.to(dev))
+    torch.cuda.synchronize()
+    assert z.shape == (1, 128, 2, 2, 2)
+    ref = OV.vae_encode(vid.float(), W, O.BF16)
+    parity.check("vae.default_encoder_9x64x64.latent_vs_oracle", rel_l2(z.float(), ref), 2.5e-2)
+
+
+# ---------------------------------------------------------------------------------------------------- (e) LoRA merge, full size
+@pytest.mark.parametrize("rank", [64, 128])
+def test_lora_merge_4096(dev, rank):
+    """lora.py:94-127 at the real projection size: W (4096,4096) += s * B(4096,r) @ A(r,4096), product in fp32,
+    bf16(W + bf16(s*BA))."""
+    from mlx_video_amd.lora import merge_lora_pair
+    g = torch.Generator().manual_seed(30 + rank)
+    Wt = (torch.randn(4096, 4096, generator=g) * 0.02).to(BF)
+    A = (torch.randn(rank, 4096, generator=g) * 0.05).to(BF)
+    B = (torch.randn(4096, rank, generator=g) * 0.05).to(BF)
+    out = merge_lora_pair(Wt.to(dev), A.to(dev), B.to(dev), 0.75)
+    torch.cuda.synchronize()
+    delta = (0.75 * (B.float() @ A.float())).to(BF).float()
+    ref = (Wt.float() + delta).to(BF)
+    diff = (out.cpu().float() - ref.float()).abs()
+    # fp32 accumulation order only: at most the last bf16 bit of the delta may differ, on a handful of elements
+    frac = float((out.cpu() != ref).float().mean())
+    parity.check(f"lora.merge_4096_rank{rank}.mismatch_fraction", frac, 2e-3)
+    parity.check(f"lora.merge_4096_rank{rank}.rel_l2", rel_l2(out.float(), ref.float()), 2e-4)
+    assert float(diff.max()) <= 2 * float(ref.float().abs().max()) * 2 ** -8

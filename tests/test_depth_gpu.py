@@ -1,0 +1,140 @@
+"""Depth / schedule-length parity: the headline runs 48 blocks x 40 steps, so a narrow
+(D=512, 4 heads) model with the REAL depth L=48 runs the REAL loops against the bf16-policy oracle:
+
+  * one forward at L=48 (per-block error accumulation over the residual stream)
+  * the 40-step CFG loop of the dev pipeline (compiled-step sigma semantics, cfg_batch, hipGraph replay)
+  * the distilled (no-CFG) loops: 8 stage-1 steps and 3 stage-2 steps, eager fp32 Euler, compiled fp32 Euler and the
+    compiled bf16 Euler (fp32_euler=False, generate.py:741-748)
+
+Measured rel-L2 values go to the parity ledger; bounds are <= 2x the MI355X measurement."""
+import pytest
+import torch
+
+import parity
+from oracle import dit as O
+from parity import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+F_, H_, W_ = 4, 4, 4
+
+
+def _deep(dev, seed=81):
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+    cfg = O.DiTConfig(num_layers=48, heads=4, caption_channels=256)
+    W = O.make_weights(cfg, seed=seed)
+    mc = LTXModelConfig(num_attention_heads=4, num_layers=48, caption_channels=256, cross_attention_dim=cfg.dim)
+    return cfg, W, LTXModel(mc, {k: v.to(dev) for k, v in W.items()})
+
+
+def _inputs(seed):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(1, 128, F_, H_, W_, generator=g).to(BF)
+    cp = torch.randn(1, 64, 256, generator=g).to(BF)
+    cn = torch.randn(1, 64, 256, generator=g).to(BF)
+    return lat, cp, cn
+
+
+def test_forward_depth48_vs_oracle(dev):
+    from mlx_video_amd.ltx_model import Modality
+    cfg, W, model = _deep(dev)
+    lat, cp, _ = _inputs(82)
+    N = F_ * H_ * W_
+    tok = lat.reshape(1, 128, N).permute(0, 2, 1).contiguous()
+    ts = torch.full((1, N), 0.6).to(BF)
+    pos = torch.from_numpy(O.create_position_grid(1, F_, H_, W_))
+    pe = O.precompute_freqs_cis(pos, cfg.dim, heads=cfg.heads)
+    v, _ = model(video=Modality(latent=tok.to(dev), timesteps=ts.to(dev), positions=pos.to(dev), context=cp.to(dev)))
+    torch.cuda.synchronize()
+    ref, hidden = O.ltx_forward(tok.float(), ts.float(), cp.float(), pe, W, cfg, O.BF16, return_hidden=True)
+    ref32 = O.ltx_forward(tok.float(), ts.float(), cp.float(), pe, W, cfg, O.F32)
+    parity.check("dit.depth48_forward.velocity_vs_bf16_oracle", rel_l2(v.float(), ref), 2e-2)
+    # context: how far the bf16 policy itself sits from pure fp32 at this depth (the reference's own storage error)
+    parity.LEDGER["dit.depth48_forward.bf16_oracle_vs_fp32_oracle"] = {"measured": rel_l2(ref, ref32), "bound": None,
+                                                                     "note": "not a product error: bf16-policy oracle vs fp32 oracle"}
+
+
+def test_dev_loop_40_steps_depth48_vs_oracle(dev):
+    """generate.py:1060-1327 with the CLI defaults of the dev pipeline: 40 steps, CFG 4.0, compiled step, cfg_batch."""
+    from mlx_video_amd.denoise import denoise_dev
+    from mlx_video_amd.schedulers import create_position_grid, ltx2_scheduler
+    cfg, W, model = _deep(dev)
+    lat, cp, cn = _inputs(83)
+    sig = ltx2_scheduler(40, F_ * H_ * W_)
+    pos = create_position_grid(1, F_, H_, W_)
+    kw = dict(cfg_scale=4.0, compile_step=True, cfg_batch=True)
+    out = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig, use_graph=True, **kw)
+    eager = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)                                   # 40 graph replays == 40 eager steps, bit for bit
+    ref = O.denoise_dev(lat.float(), pos.numpy(), cp.float(), cn.float(), W, cfg, sig.tolist(), O.BF16, 4.0, compiled=True)
+    parity.check("loop.dev_40step_cfg4_depth48.final_latents_vs_bf16_oracle", rel_l2(out.float(), ref), 4e-2)
+    # ... and the 3-step prefix, for the per-step growth of the error
+    o3 = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig[:4], **kw)
+    r3 = O.denoise_dev(lat.float(), pos.numpy(), cp.float(), cn.float(), W, cfg, sig[:4].tolist(), O.BF16, 4.0, compiled=True)
+    parity.check("loop.dev_3step_cfg4_depth48.latents_vs_bf16_oracle", rel_l2(o3.float(), r3), 2e-2)
+
+
+@pytest.mark.parametrize("mode", ["eager_fp32", "compiled_fp32", "compiled_bf16_euler"])
+def test_distilled_loops_depth48_vs_oracle(dev, mode):
+    """generate.py:564-881, the no-CFG loop, over the real stage-1 (8 steps) and stage-2 (3 steps) schedules."""
+    from mlx_video_amd.denoise import denoise_distilled
+    from mlx_video_amd.schedulers import STAGE_1_SIGMAS, STAGE_2_SIGMAS, create_position_grid
+    cfg, W, model = _deep(dev)
+    lat, cp, _ = _inputs(84)
+    pos = create_position_grid(1, F_, H_, W_)
+    compiled = mode != "eager_fp32"
+    fp32 = mode != "compiled_bf16_euler"
+    for name, sig in (("stage1_8step", list(STAGE_1_SIGMAS)), ("stage2_3step", list(STAGE_2_SIGMAS))):
+        x0 = lat if name.startswith("stage1") else (lat.float() * sig[0]).to(BF)
+        out, aud = denoise_distilled(x0.to(dev), pos.to(dev), cp.to(dev), model, sig, compile_step=compiled, fp32_euler=fp32)
+        torch.cuda.synchronize()
+        assert aud is None
+        ref = O.denoise_dev(x0.float(), pos.numpy(), cp.float(), cp.float(), W, cfg, sig, O.BF16, 1.0, compiled=compiled,
+                            bf16_euler=not fp32)
+        parity.check(f"loop.distilled_{name}_{mode}_depth48.final_latents_vs_bf16_oracle", rel_l2(out.float(), ref), 3e-2)
+    if mode == "compiled_bf16_euler":
+        # the flag must change the arithmetic (not merely be accepted): fp32 Euler on the same inputs differs
+        o32, _ = denoise_distilled(lat.to(dev), pos.to(dev), cp.to(dev), model, list(STAGE_1_SIGMAS), compile_step=True, fp32_euler=True)
+        o16, _ = denoise_distilled(lat.to(dev), pos.to(dev), cp.to(dev), model, list(STAGE_1_SIGMAS), compile_step=True, fp32_euler=False)
+        assert not torch.equal(o32, o16)
+
+
+def test_step_graph_cache_refreshes_inputs(dev):
+    """One graph_cache, two calls of the same geometry with DIFFERENT prompts, masks, clean latents and latents: the
+    second call replays the first call's captured graph and must equal the eager result for ITS inputs (the graph owns
+    persistent copies of every per-call input and refreshes them; nothing is keyed on addresses)."""
+    from mlx_video_amd.conditioning import LatentState
+    from mlx_video_amd.denoise import denoise_dev
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig
+    from mlx_video_amd.schedulers import create_position_grid, ltx2_scheduler
+    cfg = O.DiTConfig(num_layers=2, heads=4, caption_channels=256)
+    W = O.make_weights(cfg, seed=85)
+    model = LTXModel(LTXModelConfig(num_attention_heads=4, num_layers=2, caption_channels=256, cross_attention_dim=cfg.dim),
+                     {k: v.to(dev) for k, v in W.items()})
+    sig = ltx2_scheduler(5, F_ * H_ * W_)
+    pos = create_position_grid(1, F_, H_, W_).to(dev)
+    cache = {}
+    # same device buffers reused for both calls' inputs: the address-keyed cache of round 1 would replay stale data
+    lat_b = torch.empty((1, 128, F_, H_, W_), dtype=BF, device=dev)
+    cp_b = torch.empty((1, 64, 256), dtype=BF, device=dev)
+    cn_b = torch.empty((1, 64, 256), dtype=BF, device=dev)
+    clean_b = torch.empty((1, 128, F_, H_, W_), dtype=BF, device=dev)
+    mask_b = torch.empty((1, 1, F_, 1, 1), dtype=BF, device=dev)
+    for call, (seed, m0) in enumerate([(86, 0.25), (87, 0.5)]):
+        g = torch.Generator().manual_seed(seed)
+        lat_b.copy_(torch.randn(1, 128, F_, H_, W_, generator=g).to(BF))
+        cp_b.copy_(torch.randn(1, 64, 256, generator=g).to(BF))
+        cn_b.copy_(torch.randn(1, 64, 256, generator=g).to(BF))
+        clean_b.copy_(torch.randn(1, 128, F_, H_, W_, generator=g).to(BF))
+        mask = torch.ones(1, 1, F_, 1, 1)
+        mask[:, :, call] = m0                                           # a different frame AND value per call
+        mask_b.copy_(mask.to(BF))
+        state = LatentState(lat_b, clean_b, mask_b)
+        kw = dict(cfg_scale=4.0, state=state, compile_step=True, cfg_batch=True)
+        for cc in (False, True):
+            got = denoise_dev(lat_b, pos, cp_b, cn_b, model, sig, use_graph=True, graph_cache=cache, cache_context=cc, **kw)
+            want = denoise_dev(lat_b, pos, cp_b, cn_b, model, sig, cache_context=cc, **kw)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"call {call} cache_context={cc}: graph replay used stale inputs"
+    assert len(cache) == 2                                              # one entry per cache_context flavour, reused across calls
