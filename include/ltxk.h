@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LTXK_VERSION 100
+#define LTXK_VERSION 200
 
 #define LTXK_OK 0
 #define LTXK_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
@@ -37,6 +37,9 @@ extern "C" {
 
 int ltxk_version(void);
 const char* ltxk_last_error(void);
+/* sizeof the argument structs in THIS build: 0 = ltxk_gemm_args, 1 = ltxk_conv3d_args, 2 = ltxk_attn_args; anything else returns -1;
+ * lets a foreign-language binding verify its struct layout before the first call.        */
+int ltxk_abi_sizeof(int which);
 
 /* ---------------------------------------------------------------------------------------
  * GEMM with fused epilogue: replaces nn.Linear (mlx x@W.T+b) at attention.py:123-126,142,
@@ -68,6 +71,17 @@ typedef struct ltxk_gemm_args {
    * out[(b*N + n)*ldo + t]   (used for V^T so that attention reads V k-contiguous)       */
   int32_t out_tokens_per_batch;
   float alpha;          /* LTXK_EPI_SCALE_RES only                                        */
+  /* Split output (n_split > 0, a multiple of 256; EPI_BIAS): columns [0,n_split) go row-major to `out` (ldo), columns
+   * [n_split,N) transposed per batch to out2[(b*(N-n_split) + n-n_split)*ldo2 + t] with T = out_tokens_per_batch.
+   * One launch then produces q|k row-major and V^T (attention.py:123-125 as one GEMM over the packed to_q|to_k|to_v
+   * panel), or the text-side k and V^T.                                                   */
+  void* out2;
+  int32_t n_split, ldo2;
+  /* Optional (row-major columns only): sumsq[m*sumsq_ld + n/64] = sum over the 64-column block of the squares of the
+   * bf16 values stored for row m (fp32, fixed summation order).  Lets the consumer of this output (rms_norm,
+   * utils.py:398-400; q/k RMSNorm, attention.py:129-131) take its row statistic without re-reading the row.   */
+  float* sumsq;
+  int32_t sumsq_ld;
 } ltxk_gemm_args;
 
 int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
@@ -84,6 +98,27 @@ int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
  * (results then do not depend on how many (batch, head) pairs share a launch), LTXK_FA_XCD=0 the XCD-local
  * tile order, LTXK_FA_VARIANT={4,5,8} selects a kernel form.
  * ------------------------------------------------------------------------------------- */
+typedef struct ltxk_attn_args {
+  const void* q; const void* k; const void* vt; void* out;
+  int32_t ldq, ldk, ldvt, ldo;
+  int32_t B, H, Tq, Tk;
+  float scale;
+  /* Optional fused query preparation (attention.py:129-136).  With q_sumsq set, `q` holds the RAW to_q projection
+   * and the kernel applies, to its Q fragments in registers, q_norm (RMSNorm over all H*128 channels jointly, learned
+   * weight) and - if cos/sin are given - the SPLIT rotation of rope.py:109-172, with the rounding points of
+   * ltxk_qknorm_rope.  q_sumsq: (B*Tq, q_sumsq_ld) fp32, the first q_sumsq_n = H*128/64 entries of a row are the sums
+   * of squares of its 64-column blocks (the `sumsq` output of ltxk_gemm_bf16).  cos/sin: (H,Tq,64) fp32.           */
+  const float* q_sumsq;
+  int32_t q_sumsq_ld, q_sumsq_n;
+  const void* q_norm_weight;   /* (H*128) bf16 */
+  const float* cos;
+  const float* sin;
+  float eps;
+} ltxk_attn_args;
+
+int ltxk_flash_attn(const ltxk_attn_args* args, void* stream);
+
+/* The same without query preparation (positional form kept for existing bindings).       */
 int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
                          const void* vt, int32_t ldvt, void* out, int32_t ldo,
                          int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
@@ -97,6 +132,15 @@ int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
 int ltxk_rmsnorm_modulate(const void* x, void* y, int32_t M, int32_t D, float eps,
                           const void* scale, const void* shift, int32_t mod_stride,
                           const int32_t* mod_row, void* stream);
+
+/* The same when the rows' sums of squares are already known: sumsq (M, sumsq_ld) fp32, row statistic = the sum of
+ * the first sumsq_n entries (ltxk_gemm_bf16's `sumsq` output for the GEMM that produced x).  The row is then not
+ * re-read for its statistic and is split over several waves.  flags & LTXK_NORM_SCALE_IS_ONE_PLUS: `scale` already
+ * holds bf16(1+scale) (ltxk_ada_combine's one_plus_mask).                                 */
+enum { LTXK_NORM_SCALE_IS_ONE_PLUS = 1 };
+int ltxk_rmsnorm_modulate_ss(const void* x, void* y, int32_t M, int32_t D, float eps, const float* sumsq,
+                             int32_t sumsq_ld, int32_t sumsq_n, const void* scale, const void* shift,
+                             int32_t mod_stride, const int32_t* mod_row, int32_t flags, void* stream);
 
 /* LayerNorm(affine=False) + modulation of the output head: ltx.py:432-457.               */
 int ltxk_layernorm_modulate(const void* x, void* y, int32_t M, int32_t D, float eps,
@@ -114,6 +158,12 @@ int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
                      const void* weight, const float* cos, const float* sin,
                      int32_t T, int32_t H, float eps, void* stream);
 
+/* The same with the per-row sums of squares precomputed: sumsq[m*sumsq_ld + seg*(D/64) + i], i < D/64
+ * (ltxk_gemm_bf16's `sumsq` output of the projection that wrote buf).                     */
+int ltxk_qknorm_rope_ss(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
+                        const void* weight, const float* cos, const float* sin,
+                        int32_t T, int32_t H, float eps, const float* sumsq, int32_t sumsq_ld, void* stream);
+
 /* Sinusoidal timestep projection: utils.py:486-526 (flip_sin_to_cos, shift 0), applied to
  * bf16(t*mult) (ltx.py:68: timestep*timestep_scale_multiplier stays in the model dtype).
  * t: (U) bf16 timesteps; out: (U,dim) bf16.                                              */
@@ -127,9 +177,11 @@ int ltxk_rope_table(const float* positions, const float* freq, float* cos, float
                     int32_t T, int32_t H, int32_t dim, int32_t n_freq, const float* max_pos,
                     void* stream);
 
-/* out[l,u,k,:] = bf16(table[l,k,:] + ada[u,k,:]): transformer.py:135-177, ltx.py:440-447. */
+/* out[l,u,k,:] = bf16(table[l,k,:] + ada[u,k,:]): transformer.py:135-177, ltx.py:440-447.  For the k whose bit is set
+ * in one_plus_mask the stored value is bf16(1 + that) - the `(1 + scale)` factor of transformer.py:253,346, which is
+ * the same for every token that shares the row.                                           */
 int ltxk_ada_combine(const void* table, const void* ada, void* out, int32_t L, int32_t U,
-                     int32_t K, int32_t D, void* stream);
+                     int32_t K, int32_t D, uint32_t one_plus_mask, void* stream);
 
 /* Elementwise bf16 SiLU (adaln.py:45).                                                   */
 int ltxk_silu(const void* x, void* y, int64_t n, void* stream);

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LTXK_LIB", os.path.join(_HERE, "libltxk.so"))
@@ -21,6 +21,17 @@ class GemmArgs(Structure):
         ("M", c_int32), ("N", c_int32), ("K", c_int32),
         ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32), ("gate_stride", c_int32),
         ("epilogue", c_int32), ("out_tokens_per_batch", c_int32), ("alpha", c_float),
+        ("out2", c_void_p), ("n_split", c_int32), ("ldo2", c_int32), ("sumsq", c_void_p), ("sumsq_ld", c_int32),
+    ]
+
+
+class AttnArgs(Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("vt", c_void_p), ("out", c_void_p),
+        ("ldq", c_int32), ("ldk", c_int32), ("ldvt", c_int32), ("ldo", c_int32),
+        ("B", c_int32), ("H", c_int32), ("Tq", c_int32), ("Tk", c_int32), ("scale", c_float),
+        ("q_sumsq", c_void_p), ("q_sumsq_ld", c_int32), ("q_sumsq_n", c_int32),
+        ("q_norm_weight", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("eps", c_float),
     ]
 
 
@@ -39,7 +50,9 @@ class Conv3dArgs(Structure):
 SIGNATURES = {
     "ltxk_version": (c_int32, []),
     "ltxk_last_error": (c_char_p, []),
+    "ltxk_abi_sizeof": (c_int32, [c_int32]),
     "ltxk_gemm_bf16": (c_int32, [POINTER(GemmArgs), c_void_p]),
+    "ltxk_flash_attn": (c_int32, [POINTER(AttnArgs), c_void_p]),
     "ltxk_flash_attn_bf16": (c_int32, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32,
                                        c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "ltxk_rmsnorm_modulate": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32,
@@ -51,7 +64,11 @@ SIGNATURES = {
     "ltxk_timestep_embed": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "ltxk_rope_table": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                   POINTER(c_float), c_void_p]),
-    "ltxk_ada_combine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_ada_combine": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p]),
+    "ltxk_rmsnorm_modulate_ss": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p, c_int32, c_int32, c_void_p,
+                                           c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    "ltxk_qknorm_rope_ss": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                      c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "ltxk_silu": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ltxk_latent_to_tokens": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ltxk_conv3d_k3_bf16": (c_int32, [POINTER(Conv3dArgs), c_void_p]),
@@ -99,6 +116,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    for which, st in enumerate((GemmArgs, Conv3dArgs, AttnArgs)):
+        if lib.ltxk_abi_sizeof(which) != ctypes.sizeof(st):
+            raise LtxkError(f"{LIB_PATH} is stale: sizeof({st.__name__}) is {lib.ltxk_abi_sizeof(which)} in the library, "
+                            f"{ctypes.sizeof(st)} in this binding; rebuild it (make -C mlx-video_amd/csrc)")
     _lib = lib
     return lib
 

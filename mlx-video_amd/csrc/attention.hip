@@ -37,7 +37,56 @@ struct FaParams {
   int QT;    // query tiles per (batch, head)
   int xcd;   // 1: all query tiles of a (batch, head) run on one XCD (its K / V^T stay in that XCD's L2)
   int n_full, rem;   // tiles run as full workgroups / tiles split over two tail workgroups each
+  // fused query preparation (attention.py:129-136): q holds the RAW to_q output; its per-row sums of squares come as
+  // q_ss_n fp32 partials per row (the GEMM's sumsq output), the kernel applies RMSNorm (all heads jointly) * weight and
+  // the SPLIT rotation to its Q fragments in registers - the normalised / rotated q never makes a trip through HBM
+  const float* q_ss; int q_ss_ld, q_ss_n;
+  const bf16* q_w;
+  const float* cosb; const float* sinb;
+  float eps;
 };
+
+// RMSNorm * weight (+ SPLIT RoPE) of one wave's Q fragments, same op order and rounding points as qknorm_rope_kernel
+// (elementwise.hip): x = bf16(q * rstd * w); o1 = bf16(x1*c - s*x2), o2 = bf16(x2*c + s*x1) with x2 = x1's partner 64
+// channels up, which is fragment ks+4 of the same lane.
+__device__ __forceinline__ void fa_prep_q(const FaParams& p, bf16x8 (&qf)[8], int b, int h, int qrow, int hh) {
+  const int half = p.q_ss_n >> 1;
+  const float* sp = p.q_ss + (size_t)(b * p.Tq + qrow) * p.q_ss_ld + hh * half;
+  float ss = 0.f;
+  for (int i = 0; i < half; i += 4) {
+    const f32x4 v = *(const f32x4*)(sp + i);
+    ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
+  }
+  ss += __shfl_xor(ss, 32, 64);
+  const float rstd = rsqrtf(ss / (float)(p.H * FA_DH) + p.eps);
+  const bf16* wp = p.q_w + h * FA_DH + hh * 8;
+  const size_t cso = ((size_t)h * p.Tq + qrow) * 64 + hh * 8;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const bf16x8 wa = *(const bf16x8*)(wp + ks * 16), wb = *(const bf16x8*)(wp + 64 + ks * 16);
+    f32x4 c0, c1, s0, s1;
+    if (p.cosb) {
+      c0 = *(const f32x4*)(p.cosb + cso + ks * 16); c1 = *(const f32x4*)(p.cosb + cso + ks * 16 + 4);
+      s0 = *(const f32x4*)(p.sinb + cso + ks * 16); s1 = *(const f32x4*)(p.sinb + cso + ks * 16 + 4);
+    }
+    bf16x8 oa, ob;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x1 = rbf((float)qf[ks][j] * rstd * (float)wa[j]);
+      const float x2 = rbf((float)qf[ks + 4][j] * rstd * (float)wb[j]);
+      if (p.cosb) {
+        const float c = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
+        oa[j] = (bf16)(x1 * c - sn * x2);
+        ob[j] = (bf16)(x2 * c + sn * x1);
+      } else {
+        oa[j] = (bf16)x1;
+        ob[j] = (bf16)x2;
+      }
+    }
+    qf[ks] = oa;
+    qf[ks + 4] = ob;
+  }
+}
 
 // Workgroups are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  With the plain order the QT query
 // tiles of one (batch, head) land on all 8 XCDs and every L2 fetches that head's K and V^T: 8x the traffic.
@@ -145,6 +194,10 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
     const char* qreg = smem + FA_STAGE + wave * 8192 + r * 256;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qreg + (((ks * 2 + hh) ^ (r & 15)) << 4));
+  }
+  if (p.q_ss) {
+    const int qr = q0 + r < p.Tq ? q0 + r : p.Tq - 1;
+    fa_prep_q(p, qf, b, h, qr, hh);
   }
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -341,216 +394,15 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
 }
 
 
-// ---------------------------------------------------------------------------------------
-// Ping-pong form: one workgroup of 8 waves (256 query rows) per CU, K / V^T tiles in a 4-deep LDS ring
-// (128 KiB, tiles fetched three ahead).  Per tile a wave has a VALU phase X (online softmax of S(t): ~1000
-// cycles, half of it quarter-rate v_exp) and an MFMA phase Y (O += P(t).V(t), then S(t+1) = K(t+1).Q^T:
-// 32 MFMAs, ~1000 cycles).  Waves 0-3 (one per SIMD) and waves 4-7 (the second wave of each SIMD) run half a
-// tile apart - group B passes one extra barrier up front - so on every SIMD one wave's softmax runs under
-// the other wave's MFMAs instead of both waves doing the same phase at the same time.  Each K / V^T tile
-// now feeds 256 query rows: half the L2->LDS traffic of the 128-row form.
-//
-// Barrier pairing (A = waves 0-3, B = waves 4-7):   A: b0 X0 | Y0 | X1 | Y1 | ... X(n-1) | Y(n-1) | -
-//                                                   B: b0 -  | X0 | Y0 | X1 | ...          Y(n-2)| X(n-1) | Y(n-1)
-// Tile u (u >= 3) is fetched during Y(u-3) into ring slot u&3 (tile u-1's slot was last read in Y(u-1)...
-// i.e. slot (u&3) held tile u-4, last read in Y(u-4), which every wave has left).  Before the barrier that
-// opens A's Y(t) every wave has waited (vmcnt(4): all but its newest tile) for its pieces of tile t+1.
-// ---------------------------------------------------------------------------------------
-constexpr int PP_NS = 4;
-constexpr int PP_LDS = PP_NS * FA_STAGE;
-constexpr int PP_BQ = 256;
-
-#define PP_BARRIER()                                   \
-  do {                                                 \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    asm volatile("s_barrier" ::: "memory");            \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  } while (0)
-
-__global__ __launch_bounds__(512, 2) void flash_attn_pp_kernel(FaParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;
-  const int r = lane & 31, hh = lane >> 5;
-  int bh, qt;
-  fa_map(p, blockIdx.x, bh, qt);
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = qt * PP_BQ + wave * FA_QW;
-
-  int qrow = q0 + r;
-  qrow = qrow < p.Tq ? qrow : p.Tq - 1;
-  const bf16* qp = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + hh * 8;
-  bf16x8 qf[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
-
-  const int k_lrow = lane >> 4, k_slot = lane & 15;
-  const int v_lrow = lane >> 3, v_slot = lane & 7;
-  const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
-  const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
-  const int nt = (p.Tk + FA_BK - 1) / FA_BK;
-
-  // piece j (0,1: K; 2,3: V^T) of this wave for tile t -> ring slot `slot` (16 + 16 pieces dealt over 8 waves)
-  auto issue = [&](int j, int t, int slot) __attribute__((always_inline)) {
-    t = t < nt ? t : nt - 1;          // past the end: harmless re-load into a free slot (keeps vmcnt constant)
-    char* st = smem + slot * FA_STAGE;
-    const int piece = wave + 8 * (j & 1);
-    if (j < 2) {
-      const int row = piece * 4 + k_lrow;
-      int key = t * FA_BK + row;
-      key = key < p.Tk ? key : p.Tk - 1;
-      glds16(kbase + (size_t)key * p.ldk + (k_slot ^ (row & 15)) * 8, st + piece * 1024);
-    } else {
-      const int d = piece * 8 + v_lrow;
-      glds16(vbase + (size_t)d * p.ldvt + t * FA_BK + (v_slot ^ ((d >> 1) & 7)) * 8, st + FA_K_BYTES + piece * 1024);
-    }
-  };
-
-  f32x16 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  f32x16 s[2];
-
-  // fragment groups: the next group's LDS reads are requested before this group's 4 MFMAs (see fa_body)
-  bf16x8 fr[2][4];
-  auto load_k = [&](bf16x8* dst, int slot, int g) __attribute__((always_inline)) {
-    const char* sk = smem + slot * FA_STAGE;
-    const int row = (g >> 1) * 32 + fa_pi(r);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int chunk = ((g & 1) * 4 + i) * 2 + hh;
-      dst[i] = *(const bf16x8*)(sk + row * 256 + ((chunk ^ (row & 15)) << 4));
-    }
-  };
-  auto load_v = [&](bf16x8* dst, int slot, int db) __attribute__((always_inline)) {
-    const int d = db * 32 + r;
-    const char* vrow = smem + slot * FA_STAGE + FA_K_BYTES + d * 128;
-    const int sw = (d >> 1) & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = *(const bf16x8*)(vrow + ((((i >> 1) * 4 + 2 * (i & 1) + hh) ^ sw) << 4));   // i = kb*2 + sidx
-  };
-  // S = K(slot) . Q^T; fr[first] already holds (or has in flight) group 0
-  auto qk = [&](int slot, int first) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s[kb][j] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (g + 1 < 4) load_k(fr[(first + g + 1) & 1], slot, g + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[(first + g) & 1][i], qf[(g & 1) * 4 + i], s[g >> 1], 0, 0, 0);
-      }
-    }
-  };
-
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) issue(j, t, t);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  PP_BARRIER();
-  load_k(fr[0], 0, 0);
-  qk(0, 0);
-  if (grp == 1) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    PP_BARRIER();
-  }
-
-  for (int t = 0; t < nt; ++t) {
-    // ================= X: online softmax of S(t) (VALU) =================
-    if (t == nt - 1 && (p.Tk & (FA_BK - 1)) != 0) {
-      const int kbase_i = t * FA_BK + 8 * hh;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int key = kbase_i + kb * 32 + fa_acc_key(j);
-          if (key >= p.Tk) s[kb][j] = -1e30f;
-        }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kb][j]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (__any((mx - m_run) * p.c > FA_DEFER)) {      // deferred rescale, see flash_attn_kernel
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
-    }
-    const float mc = m_run * p.c;
-    float psum = 0.f;
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][j], p.c, -mc));
-        psum += e;
-        pb[kb][j >> 3][j & 7] = (bf16)e;
-      }
-    l_run += psum;
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    PP_BARRIER();
-
-    // ================= Y: O^T += V^T(t) . P^T(t);  S(t+1) = K(t+1) . Q^T  (MFMA) =================
-    load_v(fr[0], t & 3, 0);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      if (db + 1 < 4) load_v(fr[(db + 1) & 1], t & 3, db + 1);
-      else if (t + 1 < nt) load_k(fr[0], (t + 1) & 3, 0);
-      issue(db, t + 3, (t + 3) & 3);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[db & 1][i], pb[i >> 1][i & 1], o[db], 0, 0, 0);
-      }
-    }
-    if (t + 1 < nt) qk((t + 1) & 3, 0);
-    if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    PP_BARRIER();
-  }
-  if (grp == 0) PP_BARRIER();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
-  const int qout = q0 + r;
-  if (qout < p.Tq) {
-    bf16* op = p.out + ((size_t)b * p.Tq + qout) * p.ldo + h * FA_DH + 4 * hh;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4v v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
-        *(bf16x4v*)(op + db * 32 + g * 8) = v;
-      }
-  }
-}
-
 }  // namespace ltxk
 
-extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
-                                    const void* vt, int32_t ldvt, void* out, int32_t ldo,
-                                    int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
-                                    void* stream) {
+extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   using namespace ltxk;
+  LTXK_CHECK_ARG(a != nullptr, "ltxk_flash_attn: null args");
+  const void *q = a->q, *k = a->k, *vt = a->vt;
+  void* out = a->out;
+  const int32_t ldq = a->ldq, ldk = a->ldk, ldvt = a->ldvt, ldo = a->ldo, B = a->B, H = a->H, Tq = a->Tq, Tk = a->Tk;
+  const float scale = a->scale;
   LTXK_CHECK_ARG(q && k && vt && out, "ltxk_flash_attn_bf16: null pointer");
   LTXK_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0, "ltxk_flash_attn_bf16: bad dims");
   LTXK_CHECK_ARG(ldq >= H * FA_DH && ldk >= H * FA_DH && ldo >= H * FA_DH, "ltxk_flash_attn_bf16: row strides < H*128");
@@ -558,32 +410,33 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   const int tk_pad = (Tk + FA_BK - 1) / FA_BK * FA_BK;
   LTXK_CHECK_ARG(ldvt >= tk_pad && ldvt % 8 == 0, "ltxk_flash_attn_bf16: ldvt=%d must be >= %d (Tk rounded up to 64) and a multiple of 8", ldvt, tk_pad);
   LTXK_CHECK_ARG((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && ((uintptr_t)out & 15) == 0, "ltxk_flash_attn_bf16: misaligned pointer");
+  if (a->q_sumsq) {
+    LTXK_CHECK_ARG(a->q_norm_weight != nullptr, "ltxk_flash_attn: q_sumsq needs q_norm_weight");
+    LTXK_CHECK_ARG(a->q_sumsq_n > 0 && a->q_sumsq_n % 8 == 0 && a->q_sumsq_n * 64 == H * FA_DH && a->q_sumsq_ld >= a->q_sumsq_n,
+                   "ltxk_flash_attn: q_sumsq_n=%d must equal H*128/64 and be a multiple of 8", a->q_sumsq_n);
+    LTXK_CHECK_ARG((((uintptr_t)a->q_sumsq | (uintptr_t)a->q_norm_weight) & 15) == 0 && a->q_sumsq_ld % 4 == 0, "ltxk_flash_attn: q_sumsq / q_norm_weight must be 16-byte aligned");
+    LTXK_CHECK_ARG((a->cos == nullptr) == (a->sin == nullptr) && (((uintptr_t)a->cos | (uintptr_t)a->sin) & 15) == 0, "ltxk_flash_attn: cos and sin must both be set (16-byte aligned) or both NULL");
+  }
   FaParams p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.vt = (const bf16*)vt; p.out = (bf16*)out;
   p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
   p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
   p.c = scale * 1.4426950408889634f;
+  p.q_ss = a->q_sumsq; p.q_ss_ld = a->q_sumsq_ld; p.q_ss_n = a->q_sumsq_n;
+  p.q_w = (const bf16*)a->q_norm_weight; p.cosb = a->q_sumsq ? a->cos : nullptr; p.sinb = a->q_sumsq ? a->sin : nullptr; p.eps = a->eps;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev != attr_dev) {
     hipError_t e = hipFuncSetAttribute((const void*)flash_attn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)flash_attn_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
     if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
     attr_dev = dev;
   }
-  // Variants measured at B=2,H=32 (scripts/prof_attn.py; Tq=Tk=1280 / Tq=Tk=5184): 4-wave/64 KiB with the
-  // tail split (default) 630 / 945 TF/s; without the split 600 / 920; 8-wave ping-pong (variant 8) 565 / 930;
-  // 5-wave/160-row form (one exact round at 1280, but 10 waves per CU load the SIMDs 3,3,2,2) 554 / 580;
-  // a 48-KiB/3-workgroup form (register-capped at 168, spilled) ~430, removed.  Ablating the ping-pong kernel at
-  // Tq=Tk=5184 (982 us): no softmax 838, no DMA 858, neither 761, MFMAs + barriers only 636 us - i.e. the
-  // MFMA stream alone already runs at a DVFS-lowered ~1.5-1.6 GHz, and LDS reads, DMA and softmax each add
-  // 10-15 % on top; none of them alone is the bound.
-  // LTXK_FA_VARIANT={4,5,8}, LTXK_FA_XCD={1,0}, LTXK_FA_SPLIT={1,0} select forms for A/B runs.
-  static const int variant = [] { const char* e = getenv("LTXK_FA_VARIANT"); return e ? atoi(e) : 4; }();
+  // Forms measured and removed again (numbers at B=2,H=32, Tq=Tk=1280 / 5184, round 1): an 8-wave ping-pong kernel with a
+  // 4-deep 128 KiB ring 565 / 930 TF/s, a 5-wave 160-row form 554 / 580, a 48-KiB 3-workgroup form ~430, against 630 / 945
+  // for this one.  LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
-  const int rows = variant == 5 ? 160 : variant == 8 ? PP_BQ : 128;
-  p.QT = (Tq + rows - 1) / rows;
+  p.QT = (Tq + 127) / 128;
   p.xcd = (xcd_map && (B * H) % 8 == 0) ? 1 : 0;
   // read per call (not cached) so one process can A/B it: with the split on, a tile in the short round sums its
   // keys in a different order than the same rows would in a launch without a short round (e.g. B=1 vs B=2), so
@@ -598,24 +451,23 @@ extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, i
   }
   const int tiles = p.QT * B * H;
   p.n_full = tiles; p.rem = 0;
-  if (split && variant == 4 && tiles % slots != 0 && 2 * (tiles % slots) <= slots) {
+  if (split && tiles % slots != 0 && 2 * (tiles % slots) <= slots) {
     p.rem = tiles % slots;
     p.n_full = tiles - p.rem;
   }
   const dim3 grid((unsigned)(p.n_full + 2 * p.rem));
-  if (variant == 8) {
-    static thread_local int attr8_dev = -1;
-    if (dev != attr8_dev) {
-      hipError_t e = hipFuncSetAttribute((const void*)flash_attn_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
-      attr8_dev = dev;
-    }
-    hipLaunchKernelGGL(flash_attn_pp_kernel, grid, dim3(512), PP_LDS, (hipStream_t)stream, p);
-  } else if (variant == 5) {
-    hipLaunchKernelGGL(flash_attn_kernel<5>, grid, dim3(320), FA_LDS, (hipStream_t)stream, p);
-  } else {
-    hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
-  }
+  hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
   LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
   return LTXK_OK;
+}
+
+extern "C" int ltxk_flash_attn_bf16(const void* q, int32_t ldq, const void* k, int32_t ldk,
+                                    const void* vt, int32_t ldvt, void* out, int32_t ldo,
+                                    int32_t B, int32_t H, int32_t Tq, int32_t Tk, float scale,
+                                    void* stream) {
+  ltxk_attn_args a = {};
+  a.q = q; a.k = k; a.vt = vt; a.out = out;
+  a.ldq = ldq; a.ldk = ldk; a.ldvt = ldvt; a.ldo = ldo;
+  a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
+  return ltxk_flash_attn(&a, stream);
 }

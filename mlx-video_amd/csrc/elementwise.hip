@@ -3,6 +3,7 @@
 // rounding point of the reference's op chain is reproduced.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace ltxk {
 
@@ -81,6 +82,53 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
   }
 }
 
+// rms_norm + modulation when the row's sum of squares is already known (the producing GEMM's `sumsq` output: NP fp32
+// partials per row).  With the statistic precomputed nothing ties a row to one wave: a row is cut into WPR pieces of
+// 64*EPL elements, one per wave, each a short independent chain {1 partial load + x loads in flight together ->
+// 6-step wave sum -> a dozen VALU ops per element -> store}.  The wave-per-row kernel above keeps a 4096-element row
+// in one wave (8 KB of loads, then a reduction that waits for all of them, then 64 elements of arithmetic per lane):
+// at M=2560 that is 10 waves per CU each running a long serial chain, i.e. latency-bound at ~3 TB/s.
+// ONE_PLUS: `scale` already holds bf16(1 + scale) (ltxk_ada_combine's one_plus_mask), saving an add and a rounding
+// per element.
+template <int CH, bool ONE_PLUS>     // CH = 16-byte chunks per lane
+__global__ __launch_bounds__(256) void norm_scale_kernel(
+    const bf16* __restrict__ x, bf16* __restrict__ y, int M, int D, float eps, const float* __restrict__ sumsq, int ss_ld, int NP,
+    const bf16* __restrict__ scale, const bf16* __restrict__ shift, int mod_stride, const int32_t* __restrict__ mod_row) {
+  const int lane = threadIdx.x & 63;
+  const int wpr = D / (512 * CH);                                  // waves per row
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = item / wpr, piece = item - row * wpr;
+  if (row >= M) return;
+  const int col0 = piece * (512 * CH) + lane * 8;
+  const bf16* xr = x + (size_t)row * D + col0;
+  bf16x8 v[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) v[i] = *(const bf16x8*)(xr + i * 512);
+  float ss = 0.f;
+  for (int i = lane; i < NP; i += 64) ss += sumsq[(size_t)row * ss_ld + i];
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
+  bf16* yr = y + (size_t)row * D + col0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    bf16x8 o;
+    if (scale) {
+      const bf16x8 sc = *(const bf16x8*)(scale + mrow + col0 + i * 512);
+      const bf16x8 sh = *(const bf16x8*)(shift + mrow + col0 + i * 512);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = rbf((float)v[i][j] * rstd);
+        const float one_p = ONE_PLUS ? (float)sc[j] : rbf(1.0f + (float)sc[j]);
+        o[j] = (bf16)(rbf(n * one_p) + (float)sh[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)v[i][j] * rstd);
+    }
+    *(bf16x8*)(yr + i * 512) = o;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // q/k RMSNorm (full inner dim, learned weight) + SPLIT RoPE, in place.
 // One wave per (row, segment).  Lane map: a wave pass covers 8 heads; 8 lanes per head; lane holds
@@ -147,6 +195,61 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(
     }
 }
 
+// The same with the row's sum of squares precomputed (GEMM `sumsq` output, NP partials per segment): one wave per
+// (row, segment, pass of 8 heads) - 4x the waves of the kernel above at H=32, each 2 + 2 row loads deep.
+__global__ __launch_bounds__(256) void qknorm_rope_ss_kernel(
+    bf16* __restrict__ buf, int ld, int M, int nseg, int D, const bf16* __restrict__ weight,
+    const float* __restrict__ cosb, const float* __restrict__ sinb, int T, int H, float eps,
+    const float* __restrict__ sumsq, int ss_ld, int NP) {
+  const int lane = threadIdx.x & 63;
+  const int npass = (H + 7) >> 3;
+  const int item = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (item >= M * nseg * npass) return;
+  const int ps = item % npass;
+  const int rs = item / npass;
+  const int row = rs / nseg, sgi = rs - row * nseg;
+  const int t = row % T;
+  const int hl = lane >> 3, j0 = (lane & 7) * 8;
+  const int head = ps * 8 + hl;
+  bf16* xr = buf + (size_t)row * ld + (size_t)sgi * D;
+  const bf16* wr = weight + (size_t)sgi * D;
+  const bool act = head < H;
+  const int base = (act ? head : 0) * 128 + j0;
+  bf16x8 a, b;
+  if (act) {
+    a = *(const bf16x8*)(xr + base);
+    b = *(const bf16x8*)(xr + base + 64);
+  }
+  float ss = 0.f;
+  for (int i = lane; i < NP; i += 64) ss += sumsq[(size_t)row * ss_ld + sgi * NP + i];
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  if (!act) return;
+  const bf16x8 wa = *(const bf16x8*)(wr + base);
+  const bf16x8 wb = *(const bf16x8*)(wr + base + 64);
+  f32x4 c0, c1, s0, s1;
+  if (cosb) {
+    const size_t off = ((size_t)head * T + t) * 64 + j0;
+    c0 = *(const f32x4*)(cosb + off); c1 = *(const f32x4*)(cosb + off + 4);
+    s0 = *(const f32x4*)(sinb + off); s1 = *(const f32x4*)(sinb + off + 4);
+  }
+  bf16x8 oa, ob;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x1 = rbf((float)a[j] * rstd * (float)wa[j]);
+    const float x2 = rbf((float)b[j] * rstd * (float)wb[j]);
+    if (cosb) {
+      const float c = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
+      oa[j] = (bf16)(x1 * c - sn * x2);
+      ob[j] = (bf16)(x2 * c + sn * x1);
+    } else {
+      oa[j] = (bf16)x1;
+      ob[j] = (bf16)x2;
+    }
+  }
+  *(bf16x8*)(xr + base) = oa;
+  *(bf16x8*)(xr + base + 64) = ob;
+}
+
 // ---------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------
@@ -188,8 +291,8 @@ __global__ void rope_table_kernel(const float* __restrict__ pos, const float* __
 }
 
 __global__ void ada_combine_kernel(const bf16* __restrict__ table, const bf16* __restrict__ ada,
-                                   bf16* __restrict__ out, int L, int U, int K, int D) {
-  // out[l,u,k,d] = bf16(table[l,k,d] + ada[u,k,d]); 8 elements per thread
+                                   bf16* __restrict__ out, int L, int U, int K, int D, unsigned one_plus_mask) {
+  // out[l,u,k,d] = bf16(table[l,k,d] + ada[u,k,d]) (+1, rounded again, for the k in one_plus_mask); 8 elements per thread
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t kd8 = (size_t)K * D / 8;
   const size_t total = (size_t)L * U * kd8;
@@ -199,9 +302,13 @@ __global__ void ada_combine_kernel(const bf16* __restrict__ table, const bf16* _
   const int u = (int)(lu % U), l = (int)(lu / U);
   const bf16x8 a = *(const bf16x8*)(table + ((size_t)l * kd8 + e) * 8);
   const bf16x8 b = *(const bf16x8*)(ada + ((size_t)u * kd8 + e) * 8);
+  const bool op = (one_plus_mask >> (unsigned)((e * 8) / D)) & 1u;
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] + (float)b[j]);
+  for (int j = 0; j < 8; ++j) {
+    const float v = rbf((float)a[j] + (float)b[j]);
+    o[j] = (bf16)(op ? 1.0f + v : v);
+  }
   *(bf16x8*)(out + idx * 8) = o;
 }
 
@@ -321,6 +428,40 @@ extern "C" int ltxk_euler_step(const void* latent, const void* denoised, void* o
   return LTXK_OK;
 }
 
+template <int CH>
+static void norm_scale_launch(bool one_plus, dim3 grid, hipStream_t st, const bf16* x, bf16* y, int M, int D, float eps,
+                              const float* ss, int ss_ld, int np, const bf16* sc, const bf16* sh, int ms, const int32_t* mr) {
+  if (one_plus) hipLaunchKernelGGL((norm_scale_kernel<CH, true>), grid, dim3(256), 0, st, x, y, M, D, eps, ss, ss_ld, np, sc, sh, ms, mr);
+  else hipLaunchKernelGGL((norm_scale_kernel<CH, false>), grid, dim3(256), 0, st, x, y, M, D, eps, ss, ss_ld, np, sc, sh, ms, mr);
+}
+
+extern "C" int ltxk_rmsnorm_modulate_ss(const void* x, void* y, int32_t M, int32_t D, float eps, const float* sumsq,
+                                        int32_t sumsq_ld, int32_t sumsq_n, const void* scale, const void* shift,
+                                        int32_t mod_stride, const int32_t* mod_row, int32_t flags, void* stream) {
+  const char* name = "ltxk_rmsnorm_modulate_ss";
+  LTXK_CHECK_ARG(x && y && sumsq && M > 0, "%s: null/empty input", name);
+  LTXK_CHECK_ARG(D % 512 == 0 && D > 0, "%s: D=%d must be a multiple of 512", name, D);
+  LTXK_CHECK_ARG(sumsq_n > 0 && sumsq_ld >= sumsq_n, "%s: bad sumsq_n/sumsq_ld", name);
+  LTXK_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift must both be set or both NULL", name);
+  LTXK_CHECK_ARG(!scale || mod_stride % 8 == 0, "%s: mod_stride must be a multiple of 8", name);
+  // 16-byte chunks per lane: 2 (rows cut into 1024-element pieces) when D allows, else 1
+  static const int ch_env = [] { const char* e = getenv("LTXK_NORM_CH"); return e ? atoi(e) : 0; }();   // A/B runs only
+  int ch = (D % 1024 == 0) ? 2 : 1;
+  if ((ch_env == 1 || ch_env == 2 || ch_env == 4 || ch_env == 8) && D % (512 * ch_env) == 0) ch = ch_env;
+  const int wpr = D / (512 * ch);
+  const dim3 grid((unsigned)(((long long)M * wpr + 3) / 4));
+  const bool op = (flags & LTXK_NORM_SCALE_IS_ONE_PLUS) != 0;
+  hipStream_t st = (hipStream_t)stream;
+  switch (ch) {
+    case 1: norm_scale_launch<1>(op, grid, st, (const bf16*)x, (bf16*)y, M, D, eps, sumsq, sumsq_ld, sumsq_n, (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row); break;
+    case 2: norm_scale_launch<2>(op, grid, st, (const bf16*)x, (bf16*)y, M, D, eps, sumsq, sumsq_ld, sumsq_n, (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row); break;
+    case 4: norm_scale_launch<4>(op, grid, st, (const bf16*)x, (bf16*)y, M, D, eps, sumsq, sumsq_ld, sumsq_n, (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row); break;
+    default: norm_scale_launch<8>(op, grid, st, (const bf16*)x, (bf16*)y, M, D, eps, sumsq, sumsq_ld, sumsq_n, (const bf16*)scale, (const bf16*)shift, mod_stride, mod_row); break;
+  }
+  LTXK_CHECK_LAUNCH(name);
+  return LTXK_OK;
+}
+
 static int norm_modulate_launch(bool ln, const void* x, void* y, int32_t M, int32_t D, float eps,
                                 const void* scale, const void* shift, int32_t mod_stride,
                                 const int32_t* mod_row, void* stream, const char* name) {
@@ -349,6 +490,22 @@ extern "C" int ltxk_layernorm_modulate(const void* x, void* y, int32_t M, int32_
                                        const void* scale, const void* shift, int32_t mod_stride,
                                        const int32_t* mod_row, void* stream) {
   return norm_modulate_launch(true, x, y, M, D, eps, scale, shift, mod_stride, mod_row, stream, "ltxk_layernorm_modulate");
+}
+
+extern "C" int ltxk_qknorm_rope_ss(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
+                                   const void* weight, const float* cos, const float* sin,
+                                   int32_t T, int32_t H, float eps, const float* sumsq, int32_t sumsq_ld, void* stream) {
+  LTXK_CHECK_ARG(buf && weight && sumsq && M > 0 && nseg > 0, "ltxk_qknorm_rope_ss: null/empty input");
+  LTXK_CHECK_ARG(D == H * 128 && H % 4 == 0, "ltxk_qknorm_rope_ss: need D == H*128, H %% 4 == 0 (D=%d H=%d)", D, H);
+  LTXK_CHECK_ARG(ld >= nseg * D && ld % 8 == 0 && ((uintptr_t)buf & 15) == 0, "ltxk_qknorm_rope_ss: ld=%d must be >= nseg*D and a multiple of 8, buf 16-byte aligned", ld);
+  LTXK_CHECK_ARG((cos == nullptr) == (sin == nullptr), "ltxk_qknorm_rope_ss: cos and sin must both be set or both NULL");
+  LTXK_CHECK_ARG(T > 0 && sumsq_ld >= nseg * (D / 64), "ltxk_qknorm_rope_ss: T must be > 0, sumsq_ld >= nseg*D/64");
+  const int npass = (H + 7) / 8;
+  const long long items = (long long)M * nseg * npass;
+  hipLaunchKernelGGL(qknorm_rope_ss_kernel, dim3((unsigned)((items + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16*)buf, ld, M, nseg, D, (const bf16*)weight, cos, sin, T, H, eps, sumsq, sumsq_ld, D / 64);
+  LTXK_CHECK_LAUNCH("ltxk_qknorm_rope_ss");
+  return LTXK_OK;
 }
 
 extern "C" int ltxk_qknorm_rope(void* buf, int32_t ld, int32_t M, int32_t nseg, int32_t D,
@@ -391,11 +548,11 @@ extern "C" int ltxk_timestep_embed(const void* t, void* out, int32_t U, int32_t 
 }
 
 extern "C" int ltxk_ada_combine(const void* table, const void* ada, void* out, int32_t L, int32_t U,
-                                int32_t K, int32_t D, void* stream) {
-  LTXK_CHECK_ARG(table && ada && out && L > 0 && U > 0 && K > 0 && D > 0 && D % 8 == 0, "ltxk_ada_combine: bad arguments");
+                                int32_t K, int32_t D, uint32_t one_plus_mask, void* stream) {
+  LTXK_CHECK_ARG(table && ada && out && L > 0 && U > 0 && K > 0 && K <= 32 && D > 0 && D % 8 == 0, "ltxk_ada_combine: bad arguments");
   const size_t total = (size_t)L * U * K * D / 8;
   hipLaunchKernelGGL(ada_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)table, (const bf16*)ada, (bf16*)out, L, U, K, D);
+                     (const bf16*)table, (const bf16*)ada, (bf16*)out, L, U, K, D, one_plus_mask);
   LTXK_CHECK_LAUNCH("ltxk_ada_combine");
   return LTXK_OK;
 }

@@ -26,21 +26,19 @@ struct GemmParams {
   int T;  // tokens per batch for the transposed output
   float alpha;
   int wide;  // 1: rows are written as whole 128-byte lines through an LDS image (needs ldo % 8 == 0, out 16-B aligned)
+  // split output: column tiles with n0 >= n_split are written TRANSPOSED (bias only) to out2[(b*(N-n_split) + n-n_split)*ldo2 + t]
+  bf16* out2;
+  int n_split, ldo2;
+  // per-row sums of squares of the stored bf16 outputs, one fp32 per 64-column block: sumsq[m*sumsq_ld + n/64]
+  float* sumsq;
+  int sumsq_ld;
 };
 
 template <int TT, int EPI, bool TRANS>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, int wave, int lane) {
   using G = GemmGeom<TT, 4>;
   constexpr int GEMM_W_STAGE_BYTES = G::W_STAGE_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-
-  int rt, ct;
-  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
-  const int m0 = rt * G::BM, n0 = ct * GEMM_BN;
 
   // ---- loader: per-lane source pointers (row clamped, 16-byte chunk pre-swizzled) ----
   const int lrow = lane >> 3;
@@ -164,6 +162,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
       if (m >= p.M) continue;
       int grow = 0;
       if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) grow = p.gate_row ? p.gate_row[m] : 0;
+      float ss = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wn * 64 + nt * 16 + nq;
@@ -199,13 +198,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
         }
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+        for (int j = 0; j < 4; ++j) {
+          o[j] = (bf16)y[j];
+          const float f = (float)o[j];
+          ss += f * f;
+        }
         if (p.wide) {
           const int r = tt * 16 + (lane & 15), cg = lane >> 4;
           *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
         } else {
           *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
         }
+      }
+      if (p.sumsq) {
+        // the wave's 64 columns of row m: 16 values per lane, then the four lanes sharing (lane & 15); fixed order
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (lane < 16) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
       }
     }
     if (p.wide) {
@@ -221,7 +230,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     }
   } else {
     // acc[tt][nt][j]: n = lane&15, token = 4*(lane>>4) + j ; out[(b*N + n)*ldo + t]
+    // (split output: the transposed block has N - n_split rows per batch, lives in out2 and is indexed from n_split)
     const int tq = (lane >> 4) * 4;
+    bf16* const tout = p.n_split ? p.out2 : p.out;
+    const int tld = p.n_split ? p.ldo2 : p.ldo;
+    const int tN = p.N - p.n_split;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[tt][nt][j] + b);
         const int bidx = m / p.T, t = m - bidx * p.T;
-        bf16* dst = p.out + ((size_t)bidx * p.N + n) * p.ldo + t;
+        bf16* dst = tout + ((size_t)bidx * tN + (n - p.n_split)) * tld + t;
         if ((p.T & 3) == 0 && m + 3 < p.M) {
           *(bf16x4*)dst = o;
         } else {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
             const int mj = m + j;
             if (mj < p.M) {
               const int bj = mj / p.T, tj = mj - bj * p.T;
-              p.out[((size_t)bj * p.N + n) * p.ldo + tj] = o[j];
+              tout[((size_t)bj * tN + (n - p.n_split)) * tld + tj] = o[j];
             }
           }
         }
@@ -253,10 +266,32 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   }
 }
 
-template <int TT, int EPI, bool TRANS>
+// MODE 0: every tile row-major with epilogue EPI; 1: every tile transposed (V^T); 2: split output - tiles with
+// n0 < n_split row-major (EPI), the rest transposed (one launch for q|k|v, or for the text k|v pair)
+template <int TT, int EPI, int MODE>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
+  using G = GemmGeom<TT, 4>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int rt, ct;
+  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
+  const int m0 = rt * G::BM, n0 = ct * GEMM_BN;
+  if constexpr (MODE == 0) {
+    gemm_tile<TT, EPI, false>(p, smem, m0, n0, wave, lane);
+  } else if constexpr (MODE == 1) {
+    gemm_tile<TT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+  } else {
+    if (n0 < p.n_split) gemm_tile<TT, EPI, false>(p, smem, m0, n0, wave, lane);
+    else gemm_tile<TT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+  }
+}
+
+template <int TT, int EPI, int MODE>
 static int launch(const GemmParams& p, hipStream_t stream) {
   using G = GemmGeom<TT, 4>;
-  auto kern = gemm_bf16_kernel<TT, EPI, TRANS>;
+  auto kern = gemm_bf16_kernel<TT, EPI, MODE>;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -276,14 +311,15 @@ static int launch(const GemmParams& p, hipStream_t stream) {
 
 template <int TT>
 static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t stream) {
-  if (trans) return launch<TT, LTXK_EPI_BIAS, true>(p, stream);
+  if (p.n_split) return launch<TT, LTXK_EPI_BIAS, 2>(p, stream);
+  if (trans) return launch<TT, LTXK_EPI_BIAS, 1>(p, stream);
   switch (epi) {
-    case LTXK_EPI_BIAS: return launch<TT, LTXK_EPI_BIAS, false>(p, stream);
-    case LTXK_EPI_BIAS_GELU: return launch<TT, LTXK_EPI_BIAS_GELU, false>(p, stream);
-    case LTXK_EPI_BIAS_SILU: return launch<TT, LTXK_EPI_BIAS_SILU, false>(p, stream);
-    case LTXK_EPI_BIAS_GATE_RES: return launch<TT, LTXK_EPI_BIAS_GATE_RES, false>(p, stream);
-    case LTXK_EPI_BIAS_RES: return launch<TT, LTXK_EPI_BIAS_RES, false>(p, stream);
-    case LTXK_EPI_SCALE_RES: return launch<TT, LTXK_EPI_SCALE_RES, false>(p, stream);
+    case LTXK_EPI_BIAS: return launch<TT, LTXK_EPI_BIAS, 0>(p, stream);
+    case LTXK_EPI_BIAS_GELU: return launch<TT, LTXK_EPI_BIAS_GELU, 0>(p, stream);
+    case LTXK_EPI_BIAS_SILU: return launch<TT, LTXK_EPI_BIAS_SILU, 0>(p, stream);
+    case LTXK_EPI_BIAS_GATE_RES: return launch<TT, LTXK_EPI_BIAS_GATE_RES, 0>(p, stream);
+    case LTXK_EPI_BIAS_RES: return launch<TT, LTXK_EPI_BIAS_RES, 0>(p, stream);
+    case LTXK_EPI_SCALE_RES: return launch<TT, LTXK_EPI_SCALE_RES, 0>(p, stream);
   }
   ltxk_set_error("ltxk_gemm_bf16: unknown epilogue %d", epi);
   return LTXK_EINVAL;
@@ -320,13 +356,25 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   LTXK_CHECK_ARG(a->lda >= a->K && a->lda % 8 == 0, "ltxk_gemm_bf16: lda=%d (K=%d) must be >=K, multiple of 8", a->lda, a->K);
   LTXK_CHECK_ARG(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0 && ((uintptr_t)a->out & 7) == 0,
                  "ltxk_gemm_bf16: A/W must be 16-byte aligned, out 8-byte aligned");
-  const bool trans = a->out_tokens_per_batch > 0;
-  if (trans) {
+  const bool split = a->n_split > 0;
+  const bool trans = a->out_tokens_per_batch > 0 && !split;
+  if (split) {
+    LTXK_CHECK_ARG(a->epilogue == LTXK_EPI_BIAS, "ltxk_gemm_bf16: split output supports EPI_BIAS only");
+    LTXK_CHECK_ARG(a->n_split % GEMM_BN == 0 && a->n_split < a->N, "ltxk_gemm_bf16: n_split=%d must be a multiple of %d below N=%d", a->n_split, GEMM_BN, a->N);
+    LTXK_CHECK_ARG(a->out2 != nullptr && ((uintptr_t)a->out2 & 7) == 0, "ltxk_gemm_bf16: split output needs an 8-byte aligned out2");
+    LTXK_CHECK_ARG(a->out_tokens_per_batch > 0 && a->M % a->out_tokens_per_batch == 0, "ltxk_gemm_bf16: split output needs out_tokens_per_batch dividing M=%d", a->M);
+    LTXK_CHECK_ARG(a->ldo2 >= a->out_tokens_per_batch && a->ldo2 % 4 == 0, "ltxk_gemm_bf16: transposed ldo2=%d", a->ldo2);
+    LTXK_CHECK_ARG(a->ldo >= a->n_split && a->ldo % 4 == 0, "ltxk_gemm_bf16: ldo=%d (n_split=%d)", a->ldo, a->n_split);
+  } else if (trans) {
     LTXK_CHECK_ARG(a->epilogue == LTXK_EPI_BIAS, "ltxk_gemm_bf16: transposed output supports EPI_BIAS only");
     LTXK_CHECK_ARG(a->M % a->out_tokens_per_batch == 0, "ltxk_gemm_bf16: M=%d not a multiple of tokens/batch=%d", a->M, a->out_tokens_per_batch);
     LTXK_CHECK_ARG(a->ldo >= a->out_tokens_per_batch && a->ldo % 4 == 0, "ltxk_gemm_bf16: transposed ldo=%d", a->ldo);
   } else {
     LTXK_CHECK_ARG(a->ldo >= a->N && a->ldo % 4 == 0, "ltxk_gemm_bf16: ldo=%d (N=%d)", a->ldo, a->N);
+  }
+  if (a->sumsq) {
+    LTXK_CHECK_ARG(!trans && a->N % 64 == 0 && a->sumsq_ld >= (split ? a->n_split : a->N) / 64 && ((uintptr_t)a->sumsq & 3) == 0,
+                   "ltxk_gemm_bf16: sumsq needs a row-major output, N %% 64 == 0 and sumsq_ld >= columns/64");
   }
   if (a->epilogue == LTXK_EPI_BIAS_GATE_RES || a->epilogue == LTXK_EPI_BIAS_RES || a->epilogue == LTXK_EPI_SCALE_RES) {
     LTXK_CHECK_ARG(a->resid != nullptr && a->ldr >= a->N && a->ldr % 4 == 0, "ltxk_gemm_bf16: residual epilogue needs resid/ldr");
@@ -339,7 +387,9 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.out = (bf16*)a->out; p.resid = (const bf16*)a->resid; p.gate = (const bf16*)a->gate;
   p.gate_row = a->gate_row;
   p.M = a->M; p.N = a->N; p.K = a->K; p.lda = a->lda; p.ldo = a->ldo; p.ldr = a->ldr;
-  p.gate_stride = a->gate_stride; p.T = trans ? a->out_tokens_per_batch : 1; p.alpha = a->alpha;
+  p.gate_stride = a->gate_stride; p.T = (trans || split) ? a->out_tokens_per_batch : 1; p.alpha = a->alpha;
+  p.out2 = (bf16*)a->out2; p.n_split = split ? a->n_split : 0; p.ldo2 = a->ldo2;
+  p.sumsq = a->sumsq; p.sumsq_ld = a->sumsq_ld;
   static const int wide_env = [] { const char* e = getenv("LTXK_GEMM_WIDE"); return e ? atoi(e) : 1; }();
   // not for the GELU epilogue: its direct stores already issue under the activation arithmetic, and staging
   // them behind it measured 2 % slower on FF1

@@ -103,7 +103,7 @@ def precompute_freqs_cis(positions: torch.Tensor, dim: int, theta: float = 10000
 
 
 class _Block:
-    __slots__ = ("wqk", "bqk", "wv", "bv", "wnorm", "wo", "bo", "wq2", "bq2", "wk2", "bk2", "wv2", "bv2",
+    __slots__ = ("wqkv", "bqkv", "wqn", "wkn", "wo", "bo", "wq2", "bq2", "wkv2", "bkv2",
                  "wqn2", "wkn2", "wo2", "bo2", "w1", "b1", "w2", "b2")
 
 
@@ -162,14 +162,14 @@ class LTXModel:
         for i in range(cfg.num_layers):
             pre = f"transformer_blocks.{i}"
             b = _Block()
-            b.wqk = torch.cat([g(f"{pre}.attn1.to_q.weight"), g(f"{pre}.attn1.to_k.weight")], 0)
-            b.bqk = torch.cat([g(f"{pre}.attn1.to_q.bias"), g(f"{pre}.attn1.to_k.bias")], 0)
-            b.wv, b.bv = g(f"{pre}.attn1.to_v.weight"), g(f"{pre}.attn1.to_v.bias")
-            b.wnorm = torch.stack([g(f"{pre}.attn1.q_norm.weight"), g(f"{pre}.attn1.k_norm.weight")], 0)
+            # one (3D,D) panel for to_q|to_k|to_v: a single GEMM launch writes q|k row-major and V^T (split output)
+            b.wqkv = torch.cat([g(f"{pre}.attn1.to_{n}.weight") for n in "qkv"], 0)
+            b.bqkv = torch.cat([g(f"{pre}.attn1.to_{n}.bias") for n in "qkv"], 0)
+            b.wqn, b.wkn = g(f"{pre}.attn1.q_norm.weight"), g(f"{pre}.attn1.k_norm.weight")
             b.wo, b.bo = g(f"{pre}.attn1.to_out.weight"), g(f"{pre}.attn1.to_out.bias")
             b.wq2, b.bq2 = g(f"{pre}.attn2.to_q.weight"), g(f"{pre}.attn2.to_q.bias")
-            b.wk2, b.bk2 = g(f"{pre}.attn2.to_k.weight"), g(f"{pre}.attn2.to_k.bias")
-            b.wv2, b.bv2 = g(f"{pre}.attn2.to_v.weight"), g(f"{pre}.attn2.to_v.bias")
+            b.wkv2 = torch.cat([g(f"{pre}.attn2.to_k.weight"), g(f"{pre}.attn2.to_v.weight")], 0)     # text k | V^T, one launch
+            b.bkv2 = torch.cat([g(f"{pre}.attn2.to_k.bias"), g(f"{pre}.attn2.to_v.bias")], 0)
             b.wqn2, b.wkn2 = g(f"{pre}.attn2.q_norm.weight"), g(f"{pre}.attn2.k_norm.weight")
             b.wo2, b.bo2 = g(f"{pre}.attn2.to_out.weight"), g(f"{pre}.attn2.to_out.bias")
             b.w1, b.b1 = g(f"{pre}.ff.proj_in.weight"), g(f"{pre}.ff.proj_in.bias")
@@ -261,12 +261,13 @@ class LTXModel:
             k2 = torch.empty((b * s, D), dtype=BF16, device=ctx.device)
             vt2 = torch.zeros((b, D, sp), dtype=BF16, device=ctx.device) if sp != s else \
                 torch.empty((b, D, sp), dtype=BF16, device=ctx.device)
+            ss = torch.empty((b * s, D // 64), dtype=torch.float32, device=ctx.device)
         else:
-            k2, vt2 = out
-        ops.gemm(ctx, blk.wk2, blk.bk2, out=k2)
-        ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps)
-        ops.gemm(ctx, blk.wv2, blk.bv2, out=vt2, out_tokens_per_batch=s)
-        return k2, vt2
+            k2, vt2, ss = out
+        # k (row-major, with its per-row sums of squares) and V^T from one launch over the packed k|v panel
+        ops.gemm(ctx, blk.wkv2, blk.bkv2, out=k2, out2=vt2, n_split=D, out_tokens_per_batch=s, sumsq=ss)
+        ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps, sumsq=ss)
+        return k2, vt2, ss
 
     def prepare_context(self, context: torch.Tensor, out: Optional[ContextKV] = None) -> ContextKV:
         """Everything of the forward that depends on the text context only (3.37 TFLOP at S=1024, SURVEY.md
@@ -304,12 +305,17 @@ class LTXModel:
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)
 
         # --- prepare (ltx.py:129-158) ---
-        x = ops.gemm(latent.reshape(M, C), self.patchify_w, self.patchify_b)
+        # Row statistics travel with the residual stream: every GEMM that writes x also emits the per-row sums of
+        # squares of what it stored (64-column partials), so the rms_norm that follows does not re-reduce the row.
+        P = D // 64
+        xss = torch.empty((M, P), dtype=torch.float32, device=dev)
+        x = ops.gemm(latent.reshape(M, C), self.patchify_w, self.patchify_b, sumsq=xss)
         tproj = ops.timestep_embed(plan.values, 256, float(cfg.timestep_scale_multiplier))
         h = ops.gemm(tproj, self.t1_w, self.t1_b, epilogue=ops.EPI_BIAS_SILU)
         emb = ops.gemm(h, self.t2_w, self.t2_b)                           # embedded_timestep (U,D)
         ada = ops.gemm(ops.silu(emb), self.ada_w, self.ada_b)             # (U,6D)
-        mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D)  # (L,U,6,D)
+        # (L,U,6,D): shift, 1+scale, gate, shift, 1+scale, gate - the (1 + scale) factor is the same for every token of a row
+        mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D, one_plus_mask=0b010010)
         head = ops.ada_combine(self.head_table, emb.repeat(1, 2), 1, U, 2, D)[0]   # (U,2,D): shift, scale
 
         if ctx_kv is not None:
@@ -324,38 +330,42 @@ class LTXModel:
         vt = torch.zeros((B, D, np64), dtype=BF16, device=dev) if np64 != N else \
             torch.empty((B, D, np64), dtype=BF16, device=dev)
         qk = torch.empty((M, 2 * D), dtype=BF16, device=dev)
+        qkss = torch.empty((M, 2 * P), dtype=torch.float32, device=dev)
         nx = torch.empty((M, D), dtype=BF16, device=dev)
         att = torch.empty((M, D), dtype=BF16, device=dev)
         q2 = torch.empty((M, D), dtype=BF16, device=dev)
+        q2ss = torch.empty((M, P), dtype=torch.float32, device=dev)
         hff = torch.empty((M, 4 * D), dtype=BF16, device=dev)
         ms = 6 * D
         kv_buf = None
-        if ctx_kv is None:                  # text K / V^T of the current block, recomputed every forward (one buffer pair)
+        if ctx_kv is None:                  # text K / V^T of the current block, recomputed every forward (one buffer set)
             kv_buf = (torch.empty((B * S, D), dtype=BF16, device=dev),
-                      torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev))
+                      torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev),
+                      torch.empty((B * S, D // 64), dtype=torch.float32, device=dev))
 
         for li, blk in enumerate(self.blocks):
-            mod = mods[li]                                           # (U,6,D): shift,scale,gate x2
-            # self-attention (transformer.py:248-254)
-            ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx)
-            ops.gemm(nx, blk.wqk, blk.bqk, out=qk)
-            ops.gemm(nx, blk.wv, blk.bv, out=vt, out_tokens_per_batch=N)
-            ops.qknorm_rope(qk, 2, D, blk.wnorm, cos, sin, N, H, eps)
-            ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale)
+            mod = mods[li]                                           # (U,6,D): shift, 1+scale, gate x2
+            # self-attention (transformer.py:248-254).  q|k|v from one launch: q,k row-major with their row statistics,
+            # V^T transposed.  k is normalised + rotated in place; q stays RAW in HBM - the attention kernel normalises
+            # and rotates its Q fragments in registers (attention.py:129-136).
+            ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=xss, scale_is_one_plus=True)
+            ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=qkss)
+            ops.qknorm_rope(qk[:, D:], 1, D, blk.wkn, cos, sin, N, H, eps, sumsq=qkss[:, P:])
+            ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale, q_sumsq=qkss, q_norm_weight=blk.wqn,
+                           cos=cos, sin=sin, eps=eps)
             ops.gemm(att, blk.wo, blk.bo, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
-                     gate=mod[:, 2], gate_row=tok2row, gate_stride=ms)
+                     gate=mod[:, 2], gate_row=tok2row, gate_stride=ms, sumsq=xss)
             # text cross-attention (transformer.py:257-261)
-            ops.rmsnorm_modulate(x, eps, out=nx)
-            ops.gemm(nx, blk.wq2, blk.bq2, out=q2)
-            ops.qknorm_rope(q2, 1, D, blk.wqn2, None, None, N, H, eps)
+            ops.rmsnorm_modulate(x, eps, out=nx, sumsq=xss)
+            ops.gemm(nx, blk.wq2, blk.bq2, out=q2, sumsq=q2ss)
             kv = ctx_kv.kv[li] if ctx_kv is not None else self._context_kv(blk, ctx, B, S, sp64, kv_buf)
-            ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale)
-            ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x)
+            ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, q_sumsq=q2ss, q_norm_weight=blk.wqn2, eps=eps)
+            ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x, sumsq=xss)
             # feed-forward (transformer.py:343-347)
-            ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx)
+            ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx, sumsq=xss, scale_is_one_plus=True)
             ops.gemm(nx, blk.w1, blk.b1, epilogue=ops.EPI_BIAS_GELU, out=hff)
             ops.gemm(hff, blk.w2, blk.b2, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
-                     gate=mod[:, 5], gate_row=tok2row, gate_stride=ms)
+                     gate=mod[:, 5], gate_row=tok2row, gate_stride=ms, sumsq=xss)
 
         # --- output head (ltx.py:432-457) ---
         ops.layernorm_modulate(x, eps, head[:, 1], head[:, 0], 2 * D, tok2row, out=nx)

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, check
+from ._lib import AttnArgs, GemmArgs, check
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SILU, EPI_BIAS_GATE_RES, EPI_BIAS_RES, EPI_SCALE_RES = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
@@ -73,8 +73,12 @@ def _req(t: torch.Tensor, dtype, name: str) -> None:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = EPI_BIAS,
          out: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          gate: Optional[torch.Tensor] = None, gate_row: Optional[torch.Tensor] = None,
-         gate_stride: int = 0, out_tokens_per_batch: int = 0, alpha: float = 1.0) -> torch.Tensor:
-    """out = epi(a @ w.T + bias).  a (M,K) (row stride may exceed K), w (N,K) contiguous."""
+         gate_stride: int = 0, out_tokens_per_batch: int = 0, alpha: float = 1.0,
+         out2: Optional[torch.Tensor] = None, n_split: int = 0, sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias).  a (M,K) (row stride may exceed K), w (N,K) contiguous.
+    ``n_split``/``out2``: columns >= n_split go transposed per batch (out_tokens_per_batch tokens) to out2
+    (B, N-n_split, ld).  ``sumsq``: (M, >= cols/64) fp32, receives the per-64-column sums of squares of the stored
+    row-major outputs."""
     _req(a, BF16, "gemm.a"); _req(w, BF16, "gemm.w")
     M, K = a.shape
     N = w.shape[0]
@@ -84,6 +88,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
         if out_tokens_per_batch:
             raise ValueError("gemm: transposed output needs a preallocated `out`")
         out = torch.empty((M, N), dtype=BF16, device=a.device)
+    if n_split:
+        if out2 is None or out2.dtype != BF16:
+            raise ValueError("gemm: split output needs a bf16 `out2`")
+    if sumsq is not None and (sumsq.dtype != torch.float32 or sumsq.stride(-1) != 1):
+        raise TypeError("gemm: sumsq must be float32 with unit inner stride")
     args = GemmArgs()
     args.A, args.W, args.bias, args.out = _p(a), _p(w), _p(bias), _p(out)
     args.resid, args.gate, args.gate_row = _p(resid), _p(gate), _p(gate_row)
@@ -95,28 +104,56 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
     args.epilogue = epilogue
     args.out_tokens_per_batch = out_tokens_per_batch
     args.alpha = alpha
+    args.out2, args.n_split, args.ldo2 = _p(out2), n_split, (out2.stride(-2) if out2 is not None else 0)
+    args.sumsq, args.sumsq_ld = _p(sumsq), (sumsq.stride(0) if sumsq is not None else 0)
     with _timed("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
     return out
 
 
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int,
-               Tq: int, Tk: int, scale: float) -> torch.Tensor:
-    """q (B*Tq, >=H*128) view, k (B*Tk, ...) view, vt (B, H*128, ldvt), out (B*Tq, H*128)."""
+               Tq: int, Tk: int, scale: float, q_sumsq: Optional[torch.Tensor] = None,
+               q_norm_weight: Optional[torch.Tensor] = None, cos: Optional[torch.Tensor] = None,
+               sin: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    """q (B*Tq, >=H*128) view, k (B*Tk, ...) view, vt (B, H*128, ldvt), out (B*Tq, H*128).  With ``q_sumsq``
+    (B*Tq, >= H*2) the raw q projection is normalised (q_norm_weight) and rotated (cos/sin (H,Tq,64)) inside the kernel."""
+    a = AttnArgs()
+    a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
+    a.ldq, a.ldk, a.ldvt, a.ldo = q.stride(0), k.stride(0), vt.stride(-2), out.stride(0)
+    a.B, a.H, a.Tq, a.Tk, a.scale = B, H, Tq, Tk, scale
+    if q_sumsq is not None:
+        _req(q_norm_weight, BF16, "flash_attn.q_norm_weight")
+        if q_sumsq.dtype != torch.float32 or q_sumsq.stride(-1) != 1:
+            raise TypeError("flash_attn: q_sumsq must be float32 with unit inner stride")
+        if cos is not None and (cos.dtype != torch.float32 or not cos.is_contiguous() or not sin.is_contiguous()):
+            raise TypeError("flash_attn: cos/sin must be contiguous float32 (H,Tq,64)")
+        a.q_sumsq, a.q_sumsq_ld, a.q_sumsq_n = _p(q_sumsq), q_sumsq.stride(0), H * 2
+        a.q_norm_weight, a.cos, a.sin, a.eps = _p(q_norm_weight), _p(cos), _p(sin), eps
     with _timed("flash_attn", 4.0 * B * H * Tq * Tk * 128, 2.0 * B * H * 128 * (2 * Tq + 2 * Tk)):
-        check(_lib.load().ltxk_flash_attn_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(vt), vt.stride(-2),
-                                               _p(out), out.stride(0), B, H, Tq, Tk, scale, _stream()),
-              "ltxk_flash_attn_bf16")
+        check(_lib.load().ltxk_flash_attn(ctypes.byref(a), _stream()), "ltxk_flash_attn")
     return out
 
 
 def rmsnorm_modulate(x: torch.Tensor, eps: float, scale: Optional[torch.Tensor] = None,
                      shift: Optional[torch.Tensor] = None, mod_stride: int = 0,
-                     mod_row: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     mod_row: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                     sumsq: Optional[torch.Tensor] = None, scale_is_one_plus: bool = False) -> torch.Tensor:
+    """``sumsq`` (M, D/64) fp32: the rows' sums of squares in 64-column partials (gemm(..., sumsq=)); without it the
+    kernel reduces the row itself.  ``scale_is_one_plus``: scale holds bf16(1+scale) (needs sumsq)."""
     _req(x, BF16, "rmsnorm_modulate.x")
     M, D = x.shape
     if out is None:
         out = torch.empty_like(x)
+    if sumsq is not None:
+        if sumsq.dtype != torch.float32 or sumsq.stride(-1) != 1 or sumsq.shape[0] != M:
+            raise TypeError("rmsnorm_modulate: sumsq must be (M, >= D/64) float32")
+        with _timed("rmsnorm_modulate", 0.0, 4.0 * M * D):
+            check(_lib.load().ltxk_rmsnorm_modulate_ss(_p(x), _p(out), M, D, eps, _p(sumsq), sumsq.stride(0), D // 64, _p(scale),
+                                                       _p(shift), mod_stride, _p(mod_row), int(scale_is_one_plus), _stream()),
+                  "ltxk_rmsnorm_modulate_ss")
+        return out
+    if scale_is_one_plus:
+        raise ValueError("rmsnorm_modulate: scale_is_one_plus needs sumsq")
     with _timed("rmsnorm_modulate", 0.0, 4.0 * M * D):
         check(_lib.load().ltxk_rmsnorm_modulate(_p(x), _p(out), M, D, eps, _p(scale), _p(shift), mod_stride,
                                                 _p(mod_row), _stream()), "ltxk_rmsnorm_modulate")
@@ -136,11 +173,19 @@ def layernorm_modulate(x: torch.Tensor, eps: float, scale: Optional[torch.Tensor
 
 
 def qknorm_rope(buf: torch.Tensor, nseg: int, D: int, weight: torch.Tensor, cos: Optional[torch.Tensor],
-                sin: Optional[torch.Tensor], T: int, H: int, eps: float) -> torch.Tensor:
-    """In place on the first nseg*D columns of buf (M, ld)."""
+                sin: Optional[torch.Tensor], T: int, H: int, eps: float, sumsq: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """In place on the first nseg*D columns of buf (M, ld).  ``sumsq`` (M, >= nseg*D/64) fp32: precomputed partial
+    sums of squares of those columns (gemm(..., sumsq=))."""
     _req(buf, BF16, "qknorm_rope.buf")
     if cos is not None and (cos.dtype != torch.float32 or not cos.is_contiguous()):
         raise TypeError("qknorm_rope: cos/sin must be contiguous float32 (H,T,64)")
+    if sumsq is not None:
+        if sumsq.dtype != torch.float32 or sumsq.stride(-1) != 1:
+            raise TypeError("qknorm_rope: sumsq must be float32 with unit inner stride")
+        with _timed("qknorm_rope", 0.0, 4.0 * buf.shape[0] * nseg * D + (8.0 * buf.shape[0] * D // 2 if cos is not None else 0.0)):
+            check(_lib.load().ltxk_qknorm_rope_ss(_p(buf), buf.stride(0), buf.shape[0], nseg, D, _p(weight), _p(cos), _p(sin),
+                                                  T, H, eps, _p(sumsq), sumsq.stride(0), _stream()), "ltxk_qknorm_rope_ss")
+        return buf
     with _timed("qknorm_rope", 0.0, 4.0 * buf.shape[0] * nseg * D + (8.0 * buf.shape[0] * D // 2 if cos is not None else 0.0)):
         check(_lib.load().ltxk_qknorm_rope(_p(buf), buf.stride(0), buf.shape[0], nseg, D, _p(weight), _p(cos), _p(sin),
                                            T, H, eps, _stream()), "ltxk_qknorm_rope")
@@ -166,11 +211,11 @@ def rope_table(positions: torch.Tensor, freq: torch.Tensor, H: int, dim: int, ma
     return cos, sin
 
 
-def ada_combine(table: torch.Tensor, ada: torch.Tensor, L: int, U: int, K: int, D: int) -> torch.Tensor:
-    """table (L,K,D), ada (U,K*D) -> (L,U,K,D)."""
+def ada_combine(table: torch.Tensor, ada: torch.Tensor, L: int, U: int, K: int, D: int, one_plus_mask: int = 0) -> torch.Tensor:
+    """table (L,K,D), ada (U,K*D) -> (L,U,K,D); rows k with bit k of one_plus_mask set hold bf16(1 + value)."""
     _req(table, BF16, "ada_combine.table"); _req(ada, BF16, "ada_combine.ada")
     out = torch.empty((L, U, K, D), dtype=BF16, device=ada.device)
-    check(_lib.load().ltxk_ada_combine(_p(table), _p(ada), _p(out), L, U, K, D, _stream()), "ltxk_ada_combine")
+    check(_lib.load().ltxk_ada_combine(_p(table), _p(ada), _p(out), L, U, K, D, one_plus_mask, _stream()), "ltxk_ada_combine")
     return out
 
 

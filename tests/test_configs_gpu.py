@@ -97,8 +97,8 @@ def _lora_files(tmp_path, W, cfg, seed, rank=8, keys=None, name="lora.safetensor
             if keys is not None and mod not in keys:
                 continue
             o, n_in = W[key].shape
-            A = (torch.randn(rank, n_in, generator=g) * 0.05).to(BF)
-            B = (torch.randn(o, rank, generator=g) * 0.05).to(BF)
+            A = (torch.randn(rank, n_in, generator=g) * 0.1).to(BF)
+            B = (torch.randn(o, rank, generator=g) * 0.1).to(BF)
             sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_A.weight"] = A
             sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_B.weight"] = B
             pairs[key] = (A.float(), B.float())

@@ -29,7 +29,11 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libltxk.so does not export {name}"
     assert set(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ declared
-    assert lib.ltxk_version() == 100
+    hdr = open(os.path.join(ROOT, "include", "ltxk.h")).read()
+    assert lib.ltxk_version() == int(re.search(r"#define LTXK_VERSION (\d+)", hdr).group(1))
+    import ctypes
+    for which, st in enumerate((_lib.GemmArgs, _lib.Conv3dArgs, _lib.AttnArgs)):       # binding layout == compiled layout
+        assert lib.ltxk_abi_sizeof(which) == ctypes.sizeof(st)
 
 
 def test_product_refuses_cpu_tensors():

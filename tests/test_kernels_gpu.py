@@ -262,3 +262,105 @@ def test_latent_tokens_and_euler(dev):
                                  clean.to(dev) if use_mask else None, mt)
         torch.cuda.synchronize()
         assert ulp_diff_frac(out, ref, 1) < 1e-4, (use_mask, sn)
+
+
+# ---------------------------------------------------------------------------------------------------- round 2: fused forms
+@pytest.mark.parametrize("M,T,D", [(2 * 1280, 1280, 4096), (2 * 77, 77, 512), (333, 333, 1024)])
+def test_gemm_split_output_and_sumsq(dev, M, T, D):
+    """One launch over the packed q|k|v panel: columns [0,2D) row-major + their per-row sums of squares in 64-column
+    partials, columns [2D,3D) transposed per batch (V^T).  Each part must equal the separate launches bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + D)
+    a = torch.randn(M, D, generator=g).to(BF).to(dev)
+    w = (torch.randn(3 * D, D, generator=g) * 0.02).to(BF).to(dev)
+    b = (torch.randn(3 * D, generator=g) * 0.01).to(BF).to(dev)
+    B = M // T
+    Tp = (T + 63) // 64 * 64
+    qk = torch.empty(M, 2 * D, dtype=BF, device=dev)
+    vt = torch.zeros(B, D, Tp, dtype=BF, device=dev)
+    ss = torch.zeros(M, 2 * D // 64, dtype=torch.float32, device=dev)
+    ops.gemm(a, w, b, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=T, sumsq=ss)
+    qk_ref = ops.gemm(a, w[:2 * D].contiguous(), b[:2 * D].contiguous())
+    vt_ref = torch.zeros(B, D, Tp, dtype=BF, device=dev)
+    ops.gemm(a, w[2 * D:].contiguous(), b[2 * D:].contiguous(), out=vt_ref, out_tokens_per_batch=T)
+    torch.cuda.synchronize()
+    assert torch.equal(qk, qk_ref) and torch.equal(vt, vt_ref)
+    want = (qk.double() ** 2).reshape(M, -1, 64).sum(-1)
+    assert float(((ss.double() - want).abs() / want.clamp_min(1e-30)).max()) < 1e-5       # fp32 sums of exact products
+    # and against the oracle's Linear
+    ref = O.linear(a.float().cpu(), w.cpu(), b.cpu(), O.BF16)
+    parity.auto(rel_l2(qk, ref[:, :2 * D]), 2e-3)
+
+
+@pytest.mark.parametrize("mod", [False, True])
+@pytest.mark.parametrize("D", [4096, 512, 1536])
+def test_rmsnorm_modulate_with_row_stats(dev, mod, D):
+    """rms_norm + modulation with the sums of squares supplied (gemm's sumsq form) and the (1+scale) factor
+    precomputed by ada_combine's one_plus_mask: same oracle, same tolerance as the self-reducing kernel."""
+    ops = _ops()
+    M, U = 70, 3
+    g = torch.Generator().manual_seed(11 + D)
+    x = (torch.randn(M, D, generator=g) * 3).to(BF)
+    p = O.BF16
+    n = O.rms_norm(x.float(), p, 1e-6)
+    ss = (x.float() ** 2).reshape(M, D // 64, 64).sum(-1).to(dev)
+    if mod:
+        tab = torch.randn(1, 6, D, generator=g).to(BF)
+        ada = torch.randn(U, 6 * D, generator=g).to(BF)
+        rows = torch.randint(0, U, (M,), generator=g, dtype=torch.int32)
+        comb = p.r(tab.float() + ada.float().reshape(U, 6, D))                       # (U,6,D)
+        sc, sh = comb[:, 1][rows.long()], comb[:, 0][rows.long()]
+        ref = O.modulate(n, sc, sh, p)
+        mag = (n * (1 + sc)).abs() + sh.abs()
+        mods = ops.ada_combine(tab.to(dev), ada.to(dev), 1, U, 6, D, one_plus_mask=0b010010)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(mods[:, 1].float().cpu(), p.r(1.0 + comb[:, 1])) and torch.equal(mods[:, 0].float().cpu(), comb[:, 0])
+        out = ops.rmsnorm_modulate(x.to(dev), 1e-6, mods[:, 1], mods[:, 0], 6 * D, rows.to(dev), sumsq=ss, scale_is_one_plus=True)
+    else:
+        ref, mag = n, None
+        out = ops.rmsnorm_modulate(x.to(dev), 1e-6, sumsq=ss)
+    torch.cuda.synchronize()
+    assert ulp_diff_frac(out, ref, 1, mag) < 1e-3
+    parity.auto(rel_l2(out, ref), 1e-3)
+
+
+@pytest.mark.parametrize("rope", [True, False])
+@pytest.mark.parametrize("H", [32, 4])
+def test_attention_with_fused_query_prep(dev, rope, H):
+    """q_norm (+ SPLIT RoPE) applied to the Q fragments inside the attention kernel from the raw projection and its
+    row statistics, against (i) the standalone qknorm_rope kernel followed by plain attention and (ii) the oracle's
+    attention.py:129-136 + sdpa chain."""
+    ops = _ops()
+    B, F, Hh, Ww = 2, 3, 4, 5
+    T, D = F * Hh * Ww, H * 128
+    Tk = 96
+    g = torch.Generator().manual_seed(21 + H)
+    q = torch.randn(B * T, D, generator=g).to(BF)
+    k = torch.randn(B * Tk, D, generator=g).to(BF)
+    v = torch.randn(B, Tk, D, generator=g).to(BF)
+    w = (1 + 0.1 * torch.randn(1, D, generator=g)).to(BF)
+    pos = torch.from_numpy(O.create_position_grid(1, F, Hh, Ww))
+    cos, sin = O.precompute_freqs_cis(pos, D, heads=H)
+    cd, sd = (cos[0].contiguous().to(dev), sin[0].contiguous().to(dev)) if rope else (None, None)
+    vt = torch.zeros(B, D, 128, dtype=BF)
+    vt[:, :, :Tk] = v.transpose(1, 2)
+    sc = 1.0 / math.sqrt(128)
+    ss = (q.float() ** 2).reshape(B * T, D // 64, 64).sum(-1).to(dev)
+    fused = torch.empty(B * T, D, dtype=BF, device=dev)
+    ops.flash_attn(q.to(dev), k.to(dev), vt.to(dev), fused, B, H, T, Tk, sc, q_sumsq=ss, q_norm_weight=w.to(dev), cos=cd, sin=sd, eps=1e-6)
+    qn = q.to(dev).clone()
+    ops.qknorm_rope(qn, 1, D, w.to(dev), cd, sd, T, H, 1e-6)
+    two = torch.empty(B * T, D, dtype=BF, device=dev)
+    ops.flash_attn(qn, k.to(dev), vt.to(dev), two, B, H, T, Tk, sc)
+    qs = q.to(dev).clone()
+    ops.qknorm_rope(qs, 1, D, w.to(dev), cd, sd, T, H, 1e-6, sumsq=ss)                 # the stats-driven standalone form
+    torch.cuda.synchronize()
+    # same op order and rounding points; only the fp32 order of the row's sum of squares differs (1-ulp flips of rstd)
+    assert ulp_diff_frac(qs, qn, 1) < 2e-3 and rel_l2(qs, qn) < 1e-3
+    assert rel_l2(fused, two) < 2e-3
+    p = O.BF16
+    xq = O.rms_norm(q.float().reshape(B, T, D), p, 1e-6, w[0])
+    if rope:
+        xq = O.apply_split_rotary_emb(xq, cos.expand(B, -1, -1, -1), sin.expand(B, -1, -1, -1), p)
+    ref = O.sdpa(xq, k.float().reshape(B, Tk, D), v.float(), H, p)
+    parity.auto(rel_l2(fused.reshape(B, T, D), ref), 1e-2)
