@@ -22,6 +22,31 @@ def dev():
     return torch.device("cuda:0")
 
 
+def _heartbeat():
+    """On the GPU box a CPU-oracle comparison can run for minutes without output; a line per minute naming the test
+    that is running tells a long comparison from a hang."""
+    import threading
+    import time
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print(f"[progress] t={time.time() - t0:.0f}s running {os.environ.get('PYTEST_CURRENT_TEST', '?')}", file=sys.stderr, flush=True)
+
+    threading.Thread(target=beat, daemon=True).start()
+
+
+def pytest_sessionstart(session):
+    if os.environ.get("GRAFT_REPO_ROOT"):
+        _heartbeat()
+    try:        # the CPU oracle: one thread per core this process may use (a GPU box reports the whole host's cores)
+        import torch
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    except Exception:
+        pass
+
+
 def pytest_sessionfinish(session, exitstatus):
     try:
         import parity
