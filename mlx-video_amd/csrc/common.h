@@ -72,6 +72,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                : "memory");
 }
 
+// The same with the source split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset:
+// loops that walk a tensor tile by tile advance the base with scalar adds and keep the lane offsets constant.
+__device__ __forceinline__ void glds16_s(uint64_t base, unsigned lane_off, void* lds_dst) {
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_off), "s"(base), "s"(dst)
+               : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -18,6 +18,7 @@ Data layout in HBM (per GPU, bf16 unless noted):
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -103,7 +104,7 @@ def precompute_freqs_cis(positions: torch.Tensor, dim: int, theta: float = 10000
 
 
 class _Block:
-    __slots__ = ("wqkv", "bqkv", "wqn", "wkn", "wo", "bo", "wq2", "bq2", "wkv2", "bkv2",
+    __slots__ = ("wqkv", "bqkv", "wqn", "wkn", "wqkn", "wo", "bo", "wq2", "bq2", "wkv2", "bkv2",
                  "wqn2", "wkn2", "wo2", "bo2", "w1", "b1", "w2", "b2")
 
 
@@ -131,6 +132,10 @@ class LTXModel:
         self.use_middle_indices_grid = config.use_middle_indices_grid
         self.rope_type = config.rope_type
         self.timestep_scale_multiplier = config.timestep_scale_multiplier
+        # A/B switches of the launch structure (scripts/ab_step.py; all three forms give the same roundings):
+        #   1: q|k|v and text k|v as ONE GEMM launch with a split output;  2: row sums of squares carried by the GEMM
+        #   epilogues into the norm kernels;  4: q_norm + RoPE of q applied inside the attention kernel (needs 2)
+        self.fuse = int(os.environ.get("LTXK_FUSE", "7"))
         self._pack(weights)
 
     # ------------------------------------------------------------------ weights
@@ -166,6 +171,7 @@ class LTXModel:
             b.wqkv = torch.cat([g(f"{pre}.attn1.to_{n}.weight") for n in "qkv"], 0)
             b.bqkv = torch.cat([g(f"{pre}.attn1.to_{n}.bias") for n in "qkv"], 0)
             b.wqn, b.wkn = g(f"{pre}.attn1.q_norm.weight"), g(f"{pre}.attn1.k_norm.weight")
+            b.wqkn = torch.cat([b.wqn, b.wkn], 0)
             b.wo, b.bo = g(f"{pre}.attn1.to_out.weight"), g(f"{pre}.attn1.to_out.bias")
             b.wq2, b.bq2 = g(f"{pre}.attn2.to_q.weight"), g(f"{pre}.attn2.to_q.bias")
             b.wkv2 = torch.cat([g(f"{pre}.attn2.to_k.weight"), g(f"{pre}.attn2.to_v.weight")], 0)     # text k | V^T, one launch
@@ -265,8 +271,13 @@ class LTXModel:
         else:
             k2, vt2, ss = out
         # k (row-major, with its per-row sums of squares) and V^T from one launch over the packed k|v panel
-        ops.gemm(ctx, blk.wkv2, blk.bkv2, out=k2, out2=vt2, n_split=D, out_tokens_per_batch=s, sumsq=ss)
-        ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps, sumsq=ss)
+        st = ss if self.fuse & 2 else None
+        if self.fuse & 1:
+            ops.gemm(ctx, blk.wkv2, blk.bkv2, out=k2, out2=vt2, n_split=D, out_tokens_per_batch=s, sumsq=st)
+        else:
+            ops.gemm(ctx, blk.wkv2[:D], blk.bkv2[:D], out=k2, sumsq=st)
+            ops.gemm(ctx, blk.wkv2[D:], blk.bkv2[D:], out=vt2, out_tokens_per_batch=s)
+        ops.qknorm_rope(k2, 1, D, blk.wkn2, None, None, s, H, eps, sumsq=st)
         return k2, vt2, ss
 
     def prepare_context(self, context: torch.Tensor, out: Optional[ContextKV] = None) -> ContextKV:
@@ -315,7 +326,8 @@ class LTXModel:
         emb = ops.gemm(h, self.t2_w, self.t2_b)                           # embedded_timestep (U,D)
         ada = ops.gemm(ops.silu(emb), self.ada_w, self.ada_b)             # (U,6D)
         # (L,U,6,D): shift, 1+scale, gate, shift, 1+scale, gate - the (1 + scale) factor is the same for every token of a row
-        mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D, one_plus_mask=0b010010)
+        # (without the carried row statistics the self-reducing norm kernel takes the raw scale and adds 1 itself)
+        mods = ops.ada_combine(self.tables, ada, cfg.num_layers, U, 6, D, one_plus_mask=0b010010 if self.fuse & 2 else 0)
         head = ops.ada_combine(self.head_table, emb.repeat(1, 2), 1, U, 2, D)[0]   # (U,2,D): shift, scale
 
         if ctx_kv is not None:
@@ -343,29 +355,43 @@ class LTXModel:
                       torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev),
                       torch.empty((B * S, D // 64), dtype=torch.float32, device=dev))
 
+        fq, fs, fp = self.fuse & 1, self.fuse & 2, (self.fuse & 6) == 6
+        s_x, s_qk, s_q2 = (xss, qkss, q2ss) if fs else (None, None, None)
         for li, blk in enumerate(self.blocks):
             mod = mods[li]                                           # (U,6,D): shift, 1+scale, gate x2
             # self-attention (transformer.py:248-254).  q|k|v from one launch: q,k row-major with their row statistics,
             # V^T transposed.  k is normalised + rotated in place; q stays RAW in HBM - the attention kernel normalises
             # and rotates its Q fragments in registers (attention.py:129-136).
-            ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=xss, scale_is_one_plus=True)
-            ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=qkss)
-            ops.qknorm_rope(qk[:, D:], 1, D, blk.wkn, cos, sin, N, H, eps, sumsq=qkss[:, P:])
-            ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale, q_sumsq=qkss, q_norm_weight=blk.wqn,
-                           cos=cos, sin=sin, eps=eps)
+            ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
+            if fq:
+                ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=s_qk)
+            else:
+                ops.gemm(nx, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=qk, sumsq=s_qk)
+                ops.gemm(nx, blk.wqkv[2 * D:], blk.bqkv[2 * D:], out=vt, out_tokens_per_batch=N)
+            if fp:
+                ops.qknorm_rope(qk[:, D:], 1, D, blk.wkn, cos, sin, N, H, eps, sumsq=qkss[:, P:])
+                ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale, q_sumsq=qkss, q_norm_weight=blk.wqn,
+                               cos=cos, sin=sin, eps=eps)
+            else:
+                ops.qknorm_rope(qk, 2, D, blk.wqkn, cos, sin, N, H, eps, sumsq=s_qk)
+                ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale)
             ops.gemm(att, blk.wo, blk.bo, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
-                     gate=mod[:, 2], gate_row=tok2row, gate_stride=ms, sumsq=xss)
+                     gate=mod[:, 2], gate_row=tok2row, gate_stride=ms, sumsq=s_x)
             # text cross-attention (transformer.py:257-261)
-            ops.rmsnorm_modulate(x, eps, out=nx, sumsq=xss)
-            ops.gemm(nx, blk.wq2, blk.bq2, out=q2, sumsq=q2ss)
+            ops.rmsnorm_modulate(x, eps, out=nx, sumsq=s_x)
+            ops.gemm(nx, blk.wq2, blk.bq2, out=q2, sumsq=s_q2)
             kv = ctx_kv.kv[li] if ctx_kv is not None else self._context_kv(blk, ctx, B, S, sp64, kv_buf)
-            ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, q_sumsq=q2ss, q_norm_weight=blk.wqn2, eps=eps)
-            ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x, sumsq=xss)
+            if fp:
+                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, q_sumsq=q2ss, q_norm_weight=blk.wqn2, eps=eps)
+            else:
+                ops.qknorm_rope(q2, 1, D, blk.wqn2, None, None, N, H, eps, sumsq=s_q2)
+                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale)
+            ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x, sumsq=s_x)
             # feed-forward (transformer.py:343-347)
-            ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx, sumsq=xss, scale_is_one_plus=True)
+            ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
             ops.gemm(nx, blk.w1, blk.b1, epilogue=ops.EPI_BIAS_GELU, out=hff)
             ops.gemm(hff, blk.w2, blk.b2, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
-                     gate=mod[:, 5], gate_row=tok2row, gate_stride=ms, sumsq=xss)
+                     gate=mod[:, 5], gate_row=tok2row, gate_stride=ms, sumsq=s_x)
 
         # --- output head (ltx.py:432-457) ---
         ops.layernorm_modulate(x, eps, head[:, 1], head[:, 0], 2 * D, tok2row, out=nx)
