@@ -37,7 +37,6 @@ struct FaParams {
   int QT;    // query tiles per (batch, head)
   int xcd;   // 1: all query tiles of a (batch, head) run on one XCD (its K / V^T stay in that XCD's L2)
   int n_full, rem;   // tiles run as full workgroups / tiles split over two tail workgroups each
-  int prio;          // A/B (LTXK_FA_PRIO): 1 = the SIMD's odd wave slot runs at priority 1
   // fused query preparation (attention.py:129-136): q holds the RAW to_q output; its per-row sums of squares come as
   // q_ss_n fp32 partials per row (the GEMM's sumsq output), the kernel applies RMSNorm (all heads jointly) * weight and
   // the SPLIT rotation to its Q fragments in registers - the normalised / rotated q never makes a trip through HBM
@@ -208,14 +207,6 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
   if (p.q_ss) {
     const int qr = q0 + r < p.Tq ? q0 + r : p.Tq - 1;
     fa_prep_q(p, qf, b, h, qr, hh);
-  }
-  if (p.prio) {
-    // Two workgroups share a CU: each SIMD hosts one wave of each.  With equal priority the pair drifts into phase (both in
-    // their MFMA stretch, then both in their softmax); a fixed priority for the odd wave slot lets one run ahead until its
-    // softmax falls beside the partner's MFMAs.
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    if (hwid & 1) __builtin_amdgcn_s_setprio(1);
   }
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -415,357 +406,6 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
 
 
 
-// ---------------------------------------------------------------------------------------
-// flash_attn_w64_kernel: 64 query rows per wave, ONE wave per SIMD (the whole 512-entry register file), one 4-wave
-// workgroup per CU; 256 query rows share every K / V^T tile.  A wave owns two 32-row blocks A and B and runs, per
-// 64-key tile t, four phases of 16 MFMAs whose gaps carry the softmax arithmetic of the OTHER block (the matrix pipe
-// never waits for a softmax of its own; in the 32-row kernel above a wave's ~170 softmax instructions sit between its
-// two MFMA stretches and only the SIMD's second wave can cover them):
-//   P1: S_A(t)  = K(t).Q_A^T          | exp / row-sum / pack of S_B(t-1), keys 0-31
-//   P2: O_A    += V^T(t-1).P_A(t-1)   | the same for keys 32-63; running max of S_A(t); then the rescale decision for A
-//   P3: S_B(t)  = K(t).Q_B^T          | exp / row-sum / pack of S_A(t), keys 0-31
-//   P4: O_B    += V^T(t-1).P_B(t-1)   | the same for keys 32-63; running max of S_B(t); then the rescale decision for B
-// Both P.V products lag their scores by one tile, so iteration t reads K(t) and V^T(t-1) only: two ring slots per
-// operand (64 KiB) and one barrier per tile suffice; K(t+1) and V^T(t) are fetched by LDS-DMA meanwhile.
-// Every exponent is taken after the decision that covers it and every P.V of a block is complete when its decision
-// fires, so everything scaled against an old max is rescaled exactly once (the order rule of the 32-row kernel).
-// ---------------------------------------------------------------------------------------
-constexpr int W64_RING = 4 * 16384;            // K slot 0, K slot 1, V^T slot 0, V^T slot 1
-constexpr int W64_LDS = W64_RING + 4 * 16384;  // + one private 16 KiB corner per wave (Q staging, O transposition)
-constexpr int W64_BQ = 256;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define FA_SB() __builtin_amdgcn_sched_barrier(0)
-template <int V> struct FaInt { static constexpr int value = V; };
-
-__device__ __forceinline__ float fa_max3(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));      // one instruction (fmaxf pairs get canonicalising v_max in front)
-  return d;
-}
-__device__ __forceinline__ unsigned fa_cvt_pk(float lo, float hi) {
-  unsigned d;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
-  return d;
-}
-
-__global__ __launch_bounds__(256, 1) void flash_attn_w64_kernel(FaParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  int bh, qt;
-  fa_map(p, blockIdx.x, bh, qt);
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = qt * W64_BQ + wave * 64;
-  const int nt = (p.Tk + FA_BK - 1) / FA_BK;
-  char* priv = smem + W64_RING + wave * 16384;
-
-  // ---- Q: the wave's 64 x 256-byte block by LDS-DMA (whole rows) into its private corner ----
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int row = 4 * j + (lane >> 4);
-    int qrow = q0 + row;
-    qrow = qrow < p.Tq ? qrow : p.Tq - 1;
-    glds16(p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + (((lane & 15) ^ (row & 15)) << 3), priv + j * 1024);
-  }
-
-  // ---- K / V^T loader: wave-uniform tile base + tile-invariant per-lane byte offsets (see fa_body) ----
-  const int k_lrow = lane >> 4, k_slot = lane & 15;
-  const int v_lrow = lane >> 3, v_slot = lane & 7;
-  const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
-  const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
-  unsigned koff[4], voff[4];
-  const int last_ragged = (p.Tk & (FA_BK - 1)) != 0 ? (p.Tk - 1) / FA_BK : -1;
-  auto set_koff = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (wave + i * 4) * 4 + k_lrow;
-      int key = row;
-      if (t == last_ragged) key = (t * FA_BK + row < p.Tk ? t * FA_BK + row : p.Tk - 1) - t * FA_BK;
-      koff[i] = (unsigned)key * (unsigned)p.ldk * 2u + ((unsigned)(k_slot ^ (row & 15)) << 4);
-    }
-  };
-  set_koff(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int d = (wave + i * 4) * 8 + v_lrow;
-    voff[i] = (unsigned)d * (unsigned)p.ldvt * 2u + ((unsigned)(v_slot ^ ((d >> 1) & 7)) << 4);
-  }
-  const uint64_t kstep = (uint64_t)FA_BK * p.ldk * 2, vstep = FA_BK * 2;
-  // piece j (0..3: K, 4..7: V^T) of this wave: K of tile tk into K slot ks, V^T of tile tv into V^T slot vs
-  auto dma = [&](int j, int tk, int ks, int tv, int vs) __attribute__((always_inline)) {
-    if (j < 4) glds16_s((uint64_t)(uintptr_t)kbase + (uint64_t)tk * kstep, koff[j], smem + ks * 16384 + (wave + j * 4) * 1024);
-    else glds16_s((uint64_t)(uintptr_t)vbase + (uint64_t)tv * vstep, voff[j - 4], smem + 32768 + vs * 16384 + (wave + (j - 4) * 4) * 1024);
-  };
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dma(j, 0, 0, 0, 0);
-
-  // ---- fragment addresses (bytes from smem): K row fa_pi(r) (see fa_pi), V^T row r of a 32-row d block ----
-  const int pr = fa_pi(r);
-  unsigned kad[8], vad[4];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) kad[c] = pr * 256 + (((c * 2 + hh) ^ (pr & 15)) << 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) vad[i] = 32768 + r * 128 + ((((i >> 1) * 4 + 2 * (i & 1) + hh) ^ ((r >> 1) & 7)) << 4);
-  auto ldk = [&](int slot, int g, int i) __attribute__((always_inline)) {
-    return *(const bf16x8*)(smem + slot * 16384 + (g >> 1) * 8192 + kad[(g & 1) * 4 + i]);
-  };
-  auto ldv = [&](int slot, int db, int i) __attribute__((always_inline)) {
-    return *(const bf16x8*)(smem + slot * 16384 + db * 4096 + vad[i]);
-  };
-
-  f32x16 oA[4], oB[4], sA[2], sB[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { oA[i][j] = 0.f; oB[i][j] = 0.f; }
-  float mA = -1e30f, lA = 0.f, mB = -1e30f, lB = 0.f, mcA = 0.f, mcB = 0.f;
-  u32x4 pA[2][2], pB[2][2];
-  const float c = p.c;
-
-  // ---- Q fragments ----
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // the 16 Q pieces were issued before the 4 K pieces
-  bf16x8 qfA[8], qfB[8];
-  {
-    const char* qreg = priv + r * 256;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      qfA[ks] = *(const bf16x8*)(qreg + (((ks * 2 + hh) ^ (r & 15)) << 4));
-      qfB[ks] = *(const bf16x8*)(qreg + 32 * 256 + (((ks * 2 + hh) ^ (r & 15)) << 4));
-    }
-  }
-  if (p.q_ss) {
-    const int ra = q0 + r < p.Tq ? q0 + r : p.Tq - 1, rb = q0 + 32 + r < p.Tq ? q0 + 32 + r : p.Tq - 1;
-    fa_prep_q(p, qfA, b, h, ra, hh);
-    fa_prep_q(p, qfB, b, h, rb, hh);
-  }
-
-  bf16x8 f0[4], f1[4];            // rolling fragment registers: group g+1 is requested while group g multiplies
-  // S = K . Q^T (16 MFMAs); filler(idx) runs in the gap after MFMA idx; nextfr(i) requests the next phase's first fragments
-  auto qk_phase = [&](f32x16 (&S)[2], const bf16x8 (&qf)[8], int kslot, auto&& filler, auto&& nextfr) __attribute__((always_inline)) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x8 (&cur)[4] = (g & 1) ? f1 : f0;
-        bf16x8 (&nxt)[4] = (g & 1) ? f0 : f1;
-        // S is pinned to architectural VGPRs ("v"): the softmax reads it with plain VALU instructions; as a builtin hipcc
-        // accumulates S in AGPRs and copies every element out (32 v_accvgpr_read per block and tile).  hipcc does not
-        // know these MFMAs write S, so every reader is placed >= 8 MFMAs (or an explicit s_nop run) behind the last writer.
-        if ((g & 1) == 0 && i == 0)
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(S[g >> 1]) : "v"(cur[i]), "v"(qf[(g & 1) * 4 + i]));
-        else
-          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(S[g >> 1]) : "v"(cur[i]), "v"(qf[(g & 1) * 4 + i]));
-        if (g + 1 < 4) nxt[i] = ldk(kslot, g + 1, i);
-        else nextfr(nxt[i], i);
-        FA_SB();
-        filler(g * 4 + i);
-        FA_SB();
-      }
-    }
-  };
-  // O^T += V^T . P^T (16 MFMAs), same gap structure.  After 4 groups the "next" buffer is f0 again.
-  auto pv_phase = [&](f32x16 (&o)[4], const u32x4 (&pb)[2][2], int vslot, auto&& filler, auto&& nextfr) __attribute__((always_inline)) {
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x8 (&cur)[4] = (db & 1) ? f1 : f0;
-        bf16x8 (&nxt)[4] = (db & 1) ? f0 : f1;
-        // O lives in the accumulator half of the register file ("a"): only MFMAs (and the rare rescale) touch it, which
-        // leaves the 256 architectural VGPRs to S, P, Q and the fragments; left to itself hipcc moves S through AGPRs
-        // (hundreds of v_accvgpr copies per tile).  Operands: the V^T fragment comes from a compiler-counted ds_read,
-        // P was packed at least one phase earlier.
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[db]) : "v"(cur[i]), "v"(pb[i >> 1][i & 1]));
-        if (db + 1 < 4) nxt[i] = ldv(vslot, db + 1, i);
-        else nextfr(nxt[i], i);
-        FA_SB();
-        filler(db * 4 + i);
-        FA_SB();
-      }
-    }
-  };
-  // Softmax pieces, one per MFMA gap, each ONE asm statement so that it stays in its gap (hipcc otherwise gathers the
-  // row-sum adds into one block and keeps all 32 exponentials live).  Element e (0..31) of a block in step e:
-  //   t = s_e*c - m*c;  x_e = 2^t;  l += x_(e-1);  even e >= 2: P word (e-2)/2 = bf16 pair (x_(e-2), x_(e-1))
-  // (the exponential is consumed one gap later: no transcendental-result hazard inside a statement); exp_tail closes
-  // the block.  xe / xo hold the latest even / odd exponential.
-  auto exp_step = [&](const f32x16 (&S)[2], u32x4 (&P)[2][2], float mc, float& psum, float& xe, float& xo, int e) __attribute__((always_inline)) {
-    const int kb = e >> 4, j = e & 15;
-    float t;
-    if (e == 0) {
-      asm volatile("v_fma_f32 %0, %2, %3, -%4\n\ts_nop 0\n\tv_exp_f32 %1, %0" : "=&v"(t), "=v"(xe) : "v"(S[kb][j]), "s"(c), "v"(mc));
-    } else if (e & 1) {
-      asm volatile("v_fma_f32 %0, %3, %4, -%5\n\tv_add_f32 %1, %1, %6\n\tv_exp_f32 %2, %0"
-                   : "=&v"(t), "+v"(psum), "=v"(xo) : "v"(S[kb][j]), "s"(c), "v"(mc), "v"(xe));
-    } else {
-      const int w = (e - 2) >> 1;      // word of the pair just completed
-      asm volatile("v_fma_f32 %0, %4, %5, -%6\n\tv_cvt_pk_bf16_f32 %3, %2, %7\n\tv_add_f32 %1, %1, %7\n\tv_exp_f32 %2, %0"
-                   : "=&v"(t), "+v"(psum), "+v"(xe), "=&v"(P[w >> 3][(w >> 2) & 1][w & 3]) : "v"(S[kb][j]), "s"(c), "v"(mc), "v"(xo));
-    }
-  };
-  auto exp_tail = [&](u32x4 (&P)[2][2], float& psum, float xe, float xo) __attribute__((always_inline)) {
-    asm volatile("v_cvt_pk_bf16_f32 %1, %2, %3\n\tv_add_f32 %0, %0, %3" : "+v"(psum), "=&v"(P[1][1][3]) : "v"(xe), "v"(xo));
-  };
-  auto max_piece = [&](const f32x16 (&S)[2], float& mx, int idx) __attribute__((always_inline)) {
-    const int e0 = idx * 2;
-    asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(S[e0 >> 4][e0 & 15]), "v"(S[e0 >> 4][(e0 & 15) + 1]));
-  };
-  auto decide = [&](float mx, float& m_run, float& l_run, float& mc, f32x16 (&o)[4]) __attribute__((always_inline)) {
-    // row max over both lane halves: v_permlane32_swap (a VALU op; ds_bpermute would park the wave on an LDS round trip
-    // right behind the phase's last MFMA)
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-    mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    const bool grow = __any((mx - m_run) * c > FA_DEFER);
-    // The phase that just ended wrote o[3] with inline-asm MFMAs hipcc's hazard pass does not see.  From here on hipcc may
-    // touch O (the rescale below, register copies at control-flow joins and at the loop's back edge): this statement
-    // (tied to o[3], the only accumulator still in flight; a "memory" clobber would not order register reads) completes
-    // the 12 wait states an 8-pass MFMA needs before its result is read - most are already filled by the work above.
-    asm volatile("s_nop 7" : "+a"(o[3]));
-    if (grow) {                                            // deferred rescale, see fa_body
-      asm volatile("" ::: "memory");                       // keeps it a branch
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
-    }
-    mc = m_run * c;
-  };
-  auto mask_tail = [&](f32x16 (&S)[2], int t) __attribute__((always_inline)) {
-    if (t == last_ragged) {
-      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(S[0]), "+v"(S[1]));     // the phase's last MFMA must have written S
-      const int kb0 = t * FA_BK + 8 * hh;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (kb0 + kb * 32 + fa_acc_key(j) >= p.Tk) S[kb][j] = -1e30f;
-    }
-  };
-  auto nofill = [](int) __attribute__((always_inline)) {};
-  auto nonext = [](bf16x8&, int) __attribute__((always_inline)) {};
-
-  // One tile.  SLOT = t & 1: K(t) is in K slot SLOT, V^T(t-1) in V^T slot SLOT^1; K(t+1) goes to K slot SLOT^1 and
-  // V^T(t) to V^T slot SLOT.  FIRST (t == 0): there is no tile t-1 - P2 / P4 shrink to their softmax pieces.
-  auto tile = [&](auto slot_c, auto first_c, int t) __attribute__((always_inline)) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    constexpr bool FIRST = decltype(first_c)::value != 0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // K(t), V^T(t-1) visible; tile t-1 fully consumed
-    const int tn = t + 1 < nt ? t + 1 : t;                                        // last tile: harmless re-load into the free slot
-    if (tn == last_ragged && tn != t) set_koff(tn);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f0[i] = ldk(SLOT, 0, i);
-    float psB = 0.f, xeB = 0.f, xoB = 0.f, psA = 0.f, xeA = 0.f, xoA = 0.f;
-    // P1
-    qk_phase(sA, qfA, SLOT,
-             [&](int idx) __attribute__((always_inline)) {
-               if ((idx & 3) == 1) dma(idx >> 2, tn, SLOT ^ 1, t, SLOT);
-               if (!FIRST) exp_step(sB, pB, mcB, psB, xeB, xoB, idx);
-             },
-             [&](bf16x8& dst, int i) __attribute__((always_inline)) { dst = FIRST ? ldk(SLOT, 0, i) : ldv(SLOT ^ 1, 0, i); });
-    mask_tail(sA, t);
-    // P2
-    float mxA = sA[0][0];
-    if (!FIRST) {
-      pv_phase(oA, pA, SLOT ^ 1,
-               [&](int idx) __attribute__((always_inline)) {
-                 if ((idx & 3) == 1) dma(4 + (idx >> 2), tn, SLOT ^ 1, t, SLOT);
-                 exp_step(sB, pB, mcB, psB, xeB, xoB, 16 + idx);
-                 max_piece(sA, mxA, idx);
-               },
-               [&](bf16x8& dst, int i) __attribute__((always_inline)) { dst = ldk(SLOT, 0, i); });
-      exp_tail(pB, psB, xeB, xoB);
-      lB += psB;
-    } else {
-      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sA[0]), "+v"(sA[1]));
-#pragma unroll
-      for (int idx = 0; idx < 16; ++idx) max_piece(sA, mxA, idx);
-#pragma unroll
-      for (int j = 4; j < 8; ++j) dma(j, tn, SLOT ^ 1, t, SLOT);
-    }
-    decide(mxA, mA, lA, mcA, oA);
-    // P3
-    qk_phase(sB, qfB, SLOT,
-             [&](int idx) __attribute__((always_inline)) { exp_step(sA, pA, mcA, psA, xeA, xoA, idx); },
-             [&](bf16x8& dst, int i) __attribute__((always_inline)) { if (!FIRST) dst = ldv(SLOT ^ 1, 0, i); });
-    mask_tail(sB, t);
-    // P4
-    float mxB = sB[0][0];
-    if (!FIRST) {
-      pv_phase(oB, pB, SLOT ^ 1,
-               [&](int idx) __attribute__((always_inline)) {
-                 exp_step(sA, pA, mcA, psA, xeA, xoA, 16 + idx);
-                 max_piece(sB, mxB, idx);
-               },
-               nonext);
-    } else {
-      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sB[0]), "+v"(sB[1]));
-#pragma unroll
-      for (int idx = 0; idx < 16; ++idx) { exp_step(sA, pA, mcA, psA, xeA, xoA, 16 + idx); max_piece(sB, mxB, idx); }
-    }
-    exp_tail(pA, psA, xeA, xoA);
-    lA += psA;
-    decide(mxB, mB, lB, mcB, oB);
-  };
-  // after the last tile T: P.V of both blocks against V^T(T) (slot VS = T & 1), softmax of S_B(T) beside the first
-  auto drain = [&](auto vs_c) __attribute__((always_inline)) {
-    constexpr int VS = decltype(vs_c)::value;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f0[i] = ldv(VS, 0, i);
-    float psB = 0.f, xeB = 0.f, xoB = 0.f;
-    pv_phase(oA, pA, VS,
-             [&](int idx) __attribute__((always_inline)) { exp_step(sB, pB, mcB, psB, xeB, xoB, 2 * idx); exp_step(sB, pB, mcB, psB, xeB, xoB, 2 * idx + 1); },
-             [&](bf16x8& dst, int i) __attribute__((always_inline)) { dst = ldv(VS, 0, i); });
-    exp_tail(pB, psB, xeB, xoB);
-    lB += psB;
-    pv_phase(oB, pB, VS, nofill, nonext);
-    asm volatile("s_nop 15" : "+a"(oB[3]));      // the last inline-asm MFMA -> any later read or copy of O
-  };
-
-  tile(FaInt<0>{}, FaInt<1>{}, 0);
-  int t = 1;
-  for (; t + 1 < nt; t += 2) {
-    tile(FaInt<1>{}, FaInt<0>{}, t);
-    tile(FaInt<0>{}, FaInt<0>{}, t + 1);
-  }
-  if (t < nt) {
-    tile(FaInt<1>{}, FaInt<0>{}, t);
-    drain(FaInt<1>{});
-  } else {
-    drain(FaInt<0>{});
-  }
-
-  // ---- epilogue: each 32-row block transposed through the wave's private corner (whole 256-byte rows per store) ----
-  auto store_block = [&](f32x16 (&o)[4], float l_run, int qb, char* stg) __attribute__((always_inline)) {
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4v v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][g * 4 + j] * inv);
-        *(bf16x4v*)(stg + r * 256 + (((db * 4 + g) ^ (r & 15)) << 4) + hh * 8) = v;
-      }
-    bf16* ob = p.out + ((size_t)b * p.Tq) * p.ldo + h * FA_DH + (lane & 15) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = i * 4 + (lane >> 4);
-      const bf16x8 v = *(const bf16x8*)(stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
-      if (qb + row < p.Tq) *(bf16x8*)(ob + (size_t)(qb + row) * p.ldo) = v;
-    }
-  };
-  store_block(oA, lA, q0, priv);
-  store_block(oB, lB, q0 + 32, priv + 8192);
-}
-
 }  // namespace ltxk
 
 extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
@@ -806,7 +446,13 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   }
   // Forms measured and removed again (numbers at B=2,H=32, Tq=Tk=1280 / 5184, round 1): an 8-wave ping-pong kernel with a
   // 4-deep 128 KiB ring 565 / 930 TF/s, a 5-wave 160-row form 554 / 580, a 48-KiB 3-workgroup form ~430, against 630 / 945
-  // for this one.  LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
+  // for this one.  Round 2 (same box, interleaved rounds; this kernel 52.6 us at Tq=1024,Tk=1280 and 864 us at 5184^2):
+  // a 64-rows-per-wave, one-wave-per-SIMD kernel whose MFMA gaps carry the other 32-row block's softmax (accumulators
+  // pinned by inline-asm MFMAs; git 25a0404, LTXK_FA_VARIANT=64) 57.5 / 897 us (798 vs 834 us at 5120^2, where its
+  // 256-row tiles fill whole rounds); a 32-row kernel pipelined across 32-key halves 50.5 / 853 us; a fixed s_setprio
+  // for the odd wave slot of each SIMD: no change.  PMC of the 64-row form: 35 issue cycles per MFMA (4.7 VALU + 1 LDS
+  // read beside it), 18 more parked or stalled - the softmax placement is not what holds the loop at ~55 % MFMA-busy.
+  // LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
   p.QT = (Tq + 127) / 128;
   p.xcd = (xcd_map && (B * H) % 8 == 0) ? 1 : 0;
@@ -815,8 +461,6 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // batching changes low-order bits; LTXK_FA_SPLIT=0 restores batch-invariant results.
   const char* split_env = getenv("LTXK_FA_SPLIT");
   const int split = split_env ? atoi(split_env) : 1;
-  const char* prio_env = getenv("LTXK_FA_PRIO");
-  p.prio = prio_env ? atoi(prio_env) : 0;
   static thread_local int slots = 0;
   if (slots == 0) {
     int cus = 256;
@@ -828,20 +472,6 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   if (split && tiles % slots != 0 && 2 * (tiles % slots) <= slots) {
     p.rem = tiles % slots;
     p.n_full = tiles - p.rem;
-  }
-  static const int variant = [] { const char* e = getenv("LTXK_FA_VARIANT"); return e ? atoi(e) : 0; }();
-  if (variant == 64) {
-    static thread_local int attr_dev64 = -1;
-    if (dev != attr_dev64) {
-      hipError_t e = hipFuncSetAttribute((const void*)flash_attn_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W64_LDS);
-      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
-      attr_dev64 = dev;
-    }
-    p.QT = (Tq + W64_BQ - 1) / W64_BQ;
-    p.n_full = p.QT * B * H; p.rem = 0;
-    hipLaunchKernelGGL(flash_attn_w64_kernel, dim3((unsigned)p.n_full), dim3(256), W64_LDS, (hipStream_t)stream, p);
-    LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
-    return LTXK_OK;
   }
   const dim3 grid((unsigned)(p.n_full + 2 * p.rem));
   hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
