@@ -36,11 +36,27 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.
 PEAK_HBM_GBS = 8000.0
 
 
-def dit_forward_flops(N: int, B: int = 1, D: int = 4096, FF: int = 16384, S: int = 1024, L: int = 48) -> float:
-    """SURVEY.md §8d algorithmic FLOPs (2*MAC) of one DiT forward, per batch row, times B."""
+def dit_forward_flops(N: int, B: int = 1, D: int = 4096, FF: int = 16384, S: int = 1024, L: int = 48, U: int = 0) -> float:
+    """SURVEY.md §8d algorithmic FLOPs (2*MAC) of one DiT forward, per batch row, times B.  The survey's formula prices
+    the AdaLN / timestep MLPs per TOKEN (2N(256D+D^2+6D^2), what the reference executes); with ``U`` > 0 they are priced
+    for the U distinct timestep rows this implementation actually computes - used for achieved TFLOP/s."""
     per_block = 12 * N * D * D + 4 * N * D * FF + 4 * S * D * D + 4 * N * N * D + 4 * N * S * D
-    extra = 2 * N * (256 * D + D * D + 6 * D * D) + 2 * S * (3840 * D + D * D) + 4 * N * 128 * D
+    ada_rows = N if U <= 0 else U / float(B)
+    extra = 2 * ada_rows * (256 * D + D * D + 6 * D * D) + 2 * S * (3840 * D + D * D) + 4 * N * 128 * D
     return float(B) * (L * per_block + extra)
+
+
+def source_sha() -> str:
+    """Hash of the kernel sources the loaded libltxk.so was built from (the .so itself is not tracked): PMC artefacts
+    under profiles/ carry the hash they were measured on, and are only quoted while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mlx-video_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline_block(threads: int):
@@ -178,6 +194,28 @@ def main() -> None:
         dt_cached = time.perf_counter() - t2
         del gc2
 
+    # ---- second line of the same run (N even, >= 2): BASELINE config 4's CFG-pair sharding - ranks (2i, 2i+1) denoise
+    # seed i, one forward each, RCCL all-gather of the two velocities per step, fused tail on both (sharding.py) ----
+    cfgpair = None
+    if dist is not None and world >= 2 and world % 2 == 0 and pg_shard is None:
+        from mlx_video_amd.sharding import CfgPairSharding
+        sh = CfgPairSharding(dist, rank, world)
+        g3 = torch.Generator(device=dev).manual_seed(42 + rank // 2)
+        lat_p = torch.randn((1, 128, Fl, Hl, Wl), generator=g3, device=dev).to(torch.bfloat16)
+        s_p = sig_all[:args.steps + 1].clone()
+        sh.denoise_dev(lat_p, positions, ctx_pos, ctx_neg, model, s_p[:3], cfg_scale=4.0)     # builds the graphs
+        barrier()
+        t3 = time.perf_counter()
+        out_p = sh.denoise_dev(lat_p, positions, ctx_pos, ctx_neg, model, s_p, cfg_scale=4.0)
+        barrier()
+        dtp = time.perf_counter() - t3
+        tp = torch.tensor([dtp], device=dev, dtype=torch.float64)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        dtp = float(tp.item())
+        cfgpair = {"value": (world // 2) * args.steps / dtp, "unit": "denoise steps/s (whole job; one seed per rank PAIR)",
+                   "ms_per_step": 1000.0 * dtp / args.steps, "pairs": world // 2, "finite": bool(torch.isfinite(out_p.float()).all()),
+                   "collective": "all_gather_into_tensor of 2 x (1,N,128) bf16 per step per pair (RCCL)"}
+
     seeds = world if pg_shard is None else max(world // 2, 1)
     steps_per_s = seeds * args.steps / dt
     fams = timer.summary()
@@ -196,39 +234,67 @@ def main() -> None:
                    "global_batch": seeds, "tokens": N, "parallelism": f"{args.shard}{world}",
                    "ctx_kv_cached": bool(args.cache_context), "step_graph": not args.no_graph},
     }
-    step_flops = dit_forward_flops(N, B=2, L=args.layers)
+    step_flops = dit_forward_flops(N, B=2, L=args.layers)                 # SURVEY.md §8d figure (69.7 TFLOP at N=1280)
+    exec_flops = dit_forward_flops(N, B=2, L=args.layers, U=1)            # with the AdaLN MLPs priced for the U=1 row computed
     if dt_cached is not None:
         result["value_ctx_kv_cached"] = seeds * args.steps / dt_cached
         result["ms_per_step_ctx_kv_cached"] = 1000.0 * dt_cached / args.steps
     result["step_tflop"] = step_flops / 1e12
-    result["achieved_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12 * (1 if pg_shard is None else 0.5)
+    result["step_tflop_executed"] = exec_flops / 1e12
+    result["achieved_tflops_per_gpu"] = exec_flops * args.steps / dt / 1e12 * (1 if pg_shard is None else 0.5)
+    # ---- roofline: one entry per kernel family, measured live (HIP events around every launch of the instrumented
+    # pass, on the launch stream).  achieved = algorithmic FLOPs (or bytes) of the family / its summed launch time.
+    rooflines = {}
     if "gemm_bf16" in fams:
         gm = fams["gemm_bf16"]
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         traffic = None
-        try:   # HBM-side bytes of the dominant GEMM launch (FF1) from the committed PMC passes (gfx950-corrected)
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            k = next(v for n, v in pm["kernels"].items() if "FF1" in n)
-            traffic = {"bytes_per_launch": k["read_bytes_corrected"] + k["write_bytes"], "algorithmic_bytes": k["algorithmic_bytes"],
-                       "kernel": "FF1 GEMM M=2560 N=16384 K=4096", "source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+        try:   # L2->fabric bytes of the dominant GEMM launch (FF1) from separate --pmc passes (gfx950-corrected);
+            # quoted only while the kernel sources still hash to what the passes were measured on
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if pm.get("source_sha") == source_sha():
+                k = next(v for n, v in pm["kernels"].items() if "FF1" in n)
+                traffic = {"bytes_per_launch": k["read_bytes_corrected"] + k["write_bytes"], "algorithmic_bytes": k["algorithmic_bytes"],
+                           "kernel": "FF1 GEMM M=2560 N=16384 K=4096", "source_sha": pm["source_sha"],
+                           "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
         except Exception:
             pass
-        result["roofline"] = {"kernel": "ltxk::gemm_bf16_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
-                              "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
-                              "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"]}
-    result["kernel_breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fams.items()}
+        rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
+                                  "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
+                                  "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"]}
     if "flash_attn" in fams:
         fa = fams["flash_attn"]
-        result["attention_tflops"] = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
+        ach = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
+        rooflines["flash_attn"] = {"kernel": "ltxk::flash_attn_kernel (4*B*H*Tq*Tk*128 FLOP per launch)", "bound": "mfma", "achieved": ach,
+                                   "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                                   "launches": fa["launches"], "avg_ms": fa["ms"] / fa["launches"]}
+        result["attention_tflops"] = ach
     for k in ("rmsnorm_modulate", "qknorm_rope"):
         if k in fams and fams[k]["ms"] > 0:
-            result[f"{k}_GBs"] = fams[k]["bytes"] / (fams[k]["ms"] * 1e-3) / 1e9
+            gbs = fams[k]["bytes"] / (fams[k]["ms"] * 1e-3) / 1e9
+            rooflines[k] = {"kernel": f"ltxk {k} (algorithmic bytes: read x [+ tables], write y)", "bound": "hbm", "achieved": gbs,
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                            "launches": fams[k]["launches"], "avg_ms": fams[k]["ms"] / fams[k]["launches"]}
+            result[f"{k}_GBs"] = gbs
+    if "gemm_bf16" in rooflines:
+        result["roofline"] = rooflines["gemm_bf16"]          # the dominant kernel (85 % of the step)
+    result["roofline_by_family"] = rooflines
+    result["kernel_breakdown_ms_per_step"] = {k: v["ms"] / args.steps for k, v in fams.items()}
+    result["kernel_source_sha"] = source_sha()
+    if cfgpair is not None:
+        result["cfgpair"] = cfgpair
 
     if not args.no_vae:
         try:
             from mlx_video_amd import video_vae
-            result.update(video_vae.bench_decode(dev, Fl, Hl, Wl))
+            vres = video_vae.bench_decode(dev, Fl, Hl, Wl)
+            result.update(vres)
+            if "vae_conv3d_tflops" in vres:
+                result["roofline_by_family"]["conv3d_k3"] = {
+                    "kernel": "ltxk::conv3d_k3_kernel (2*27*Cin*Cout*voxels FLOP per launch)", "bound": "mfma",
+                    "achieved": vres["vae_conv3d_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                    "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None}
         except ImportError:
             result["vae_decode_fps"] = None
 
