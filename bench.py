@@ -104,7 +104,10 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device(f"cuda:{local_rank}")
+    # LTXK_BENCH_REHEARSAL=1 (builder's one-GPU box only): all ranks share cuda:0 and talk over gloo, to execute the N>1
+    # code paths of this file without an 8-GPU node; numbers from such a run are not throughput measurements.
+    rehearsal = os.environ.get("LTXK_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda:0" if rehearsal else f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
@@ -113,7 +116,10 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", str(world))
-        dist_mod.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist_mod.init_process_group("gloo")
+        else:
+            dist_mod.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
         dist = dist_mod
 
     from mlx_video_amd import ops

@@ -40,6 +40,19 @@ for r in range(R):
             graphs[v].replay()
         torch.cuda.synchronize()
         times[v].append((time.perf_counter() - t0) / 4 * 1e3)
+if os.environ.get("AB_EAGER") == "1":
+    for v in VARIANTS:
+        model.fuse = v
+        ts = []
+        for r in range(R):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                model.forward_tokens(lat, plan, ctx, pe)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 4 * 1e3)
+        ts.sort()
+        print(json.dumps({"fuse": v, "eager_ms_forward_median": ts[len(ts) // 2], "eager_ms_min": ts[0]}), flush=True)
 base = outs[VARIANTS[0]].float()
 for v in VARIANTS:
     t = sorted(times[v])
