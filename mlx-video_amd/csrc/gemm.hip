@@ -4,14 +4,45 @@
 // transformer.py:254,257,347 as epilogues.
 #include "gemm_core.h"
 #include <stdlib.h>
+#include <utility>
 
 #ifndef LTXK_STAGGER
 #define LTXK_STAGGER 0   // measured neutral (profiles/r01 notes); kept for A/B
 #endif
 
+#ifdef LTXK_DIAG
+// Diagnostic build only (make diag -> libltxk_diag.so): per-workgroup phase stamps (s_memrealtime, 100 MHz) written to a
+// buffer of their own; the product library contains none of this.
+__device__ unsigned long long* ltxk_gemm_stamps = nullptr;
+extern "C" int ltxk_diag_set_gemm_stamps(void* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ltxk_gemm_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define LTXK_STAMP(slot)                                                                              \
+  do {                                                                                                \
+    if (ltxk_gemm_stamps && threadIdx.x == 0) ltxk_gemm_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define LTXK_STAMP(slot) do { } while (0)
+#endif
+
+// The counted vmcnt waits below assume a FIXED number of loads per lane between the DMA pieces.  `load(c ? a : dummy)`
+// whose value is only used when c holds gets unfolded by the optimiser into a load under `if (c)`: with bias == NULL a
+// LoRA merge then issued four loads fewer than its first wait allows in flight and raced its first stage.  The source
+// pointer is therefore made opaque first (an empty asm: no instruction, no wait), which leaves ONE unconditional load.
+// (The pointer comes back as an explicit global-address-space pointer: a generic one would turn the load into flat_load,
+// which hipcc waits for with vmcnt(0).)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* opaque_gptr(const T* p) {
+  uintptr_t u = (uintptr_t)p;
+  asm volatile("" : "+v"(u));
+  return (const __attribute__((address_space(1))) T*)u;
+}
+#define LTXK_VLOAD(T, ptr) (*opaque_gptr<T>((const T*)(ptr)))
+
 namespace ltxk {
 
 constexpr int GEMM_BN = 256;
+template <int V> struct IntC { static constexpr int value = V; };
 
 struct GemmParams {
   const bf16* A;
@@ -79,26 +110,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     }
   };
 
-  // Residual epilogues: this tile's residual values are requested now (40 VGPRs at TT=5) and arrive under the
-  // main loop, instead of as a 21 MB read burst issued by every workgroup at once when the loop ends.  (The
-  // output may alias the residual: each element is read and written by this workgroup only.)
   constexpr bool HAS_RES = !TRANS && (EPI == LTXK_EPI_BIAS_GATE_RES || EPI == LTXK_EPI_BIAS_RES || EPI == LTXK_EPI_SCALE_RES);
-  bf16x4 rres[HAS_RES ? TT : 1][4];
-  if constexpr (HAS_RES) {
-    const int nq = (lane >> 4) * 4;
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
-      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
-      m = m < p.M ? m : p.M - 1;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        int n = n0 + wn * 64 + nt * 16 + nq;
-        n = n < p.N ? n : p.N - 4;
-        rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
-      }
-    }
-  }
-
+  constexpr bool HAS_GATE = !TRANS && EPI == LTXK_EPI_BIAS_GATE_RES;
   f32x4 acc[TT][4];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
@@ -106,25 +119,128 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GEMM_BK;
+  LTXK_STAMP(0);
+  // Epilogue operands (bias, residual tile, gate rows) are requested up front and arrive under the main loop instead
+  // of as a dependent-load chain (gate_row -> gate -> arithmetic) and a 21 MB residual burst when the loop ends.  They
+  // are issued BEHIND the first two stages' DMA pieces - vmcnt retires in issue order, so the first K-steps wait with a
+  // counted vmcnt that leaves these loads in flight (issued in front, the first barrier waited for all of them: 4-5 us
+  // per launch by in-kernel stamps).  The number of loads per lane is a compile-time constant (dummy sources stand in
+  // for absent operands), as the counted waits need.  (The output may alias the residual: each element is read and
+  // written by this workgroup only.)
+  int grow[HAS_GATE ? TT : 1];
+  if constexpr (HAS_GATE) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
+      grow[tt] = LTXK_VLOAD(int32_t, p.gate_row ? p.gate_row + m : (const int32_t*)p.W);      // (dummy source keeps the load count fixed)
+    }
+  }
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0);
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
-  int s = 0;
-  if constexpr (TT >= 2) {
-    auto kloop = [&](auto& pipe) __attribute__((always_inline)) {
-      pipe.init();
-      for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once all but the youngest PER_STAGE pieces (stage kt+1) are done
-        wait_stage_and_barrier(PER_STAGE);
-        int s2 = s + 2;
-        s2 = s2 >= 3 ? s2 - 3 : s2;
-        const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
-        pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
-        s = s + 1 == 3 ? 0 : s + 1;
+  bf16x4 rres[HAS_RES ? TT : 1][4], bpre[4], gpre[HAS_GATE ? TT : 1][4];
+  bf16 bpre_t[4];
+  // The residual tile (21 MB per launch over the chip) is NOT requested here: read as one burst in the prologue it holds
+  // up the first stages' arrival by ~4 us (the fabric serves it at ~5 TB/s; in-kernel stamps).  It trickles in during
+  // K-steps 2 .. 1+TT, one 16-row band (4 loads per lane) per step; bands a short K (a LoRA merge: 1-2 steps) never
+  // reaches are read after the loop.  (One writer per register on every path: with a second, "all bands up front"
+  // path for short K, hipcc guarded the in-loop loads against the other path's possibly pending ones with
+  // vmcnt(16) ... vmcnt(0) - a drain of the DMA pipeline in each of the steps.)
+  auto load_res_band = [&](auto tt_c) __attribute__((always_inline)) {
+    constexpr int tt = decltype(tt_c)::value;
+    if constexpr (HAS_RES && tt < TT) {
+      const int nq = (lane >> 4) * 4;
+      int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      m = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        rres[tt][nt] = LTXK_VLOAD(bf16x4, p.resid + (size_t)m * p.ldr + n);
       }
-      pipe.finish(acc);
-    };
+    }
+  };
+  constexpr int NB = 4;                                           // bias loads per lane, issued behind stage 1
+  constexpr int NX2 = HAS_GATE ? TT * 4 : 0;                      // gate values, issued after the first barrier
+  {
+    const int nq = (lane >> 4) * 4;
+    if constexpr (TRANS) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+        n = n < p.N ? n : p.N - 1;
+        bpre_t[nt] = LTXK_VLOAD(bf16, p.bias ? p.bias + n : p.W);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        int n = n0 + wn * 64 + nt * 16 + nq;
+        n = n < p.N ? n : p.N - 4;
+        bpre[nt] = LTXK_VLOAD(bf16x4, p.bias ? p.bias + n : p.W);
+      }
+    }
+  }
+  auto issue_gate = [&]() __attribute__((always_inline)) {
+    if constexpr (HAS_GATE) {
+      const int nq = (lane >> 4) * 4;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int gr = p.gate_row ? grow[tt] : 0;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          int n = n0 + wn * 64 + nt * 16 + nq;
+          n = n < p.N ? n : p.N - 4;
+          gpre[tt][nt] = LTXK_VLOAD(bf16x4, p.gate + (size_t)gr * p.gate_stride + n);
+        }
+      }
+    }
+  };
+  // K-steps.  Stage kt is waited for with a counted vmcnt that leaves in flight everything issued behind its pieces
+  // (vmcnt retires in issue order):
+  //   kt = 0: stage 1 + the bias loads;  kt = 1: those + the gate loads + stage 2;
+  //   kt >= 2: stage kt+1 + the residual band requested at the start of step kt-1.
+  // The first PEEL steps are unrolled with a compile-time kt: the epilogue-operand loads then sit in straight-line code
+  // and land directly in their final registers.  (Issued from inside the loop - a switch on kt - hipcc loaded them into
+  // temporaries and put `s_waitcnt vmcnt(0)` + copies INTO the loop: 72 -> 90 us at K=4096.)
+  constexpr int PEEL = HAS_RES ? 3 + TT : 2;
+  int s = 0;
+  auto kstep = [&](auto& pipe, int kt, auto kc) __attribute__((always_inline)) {
+    constexpr int KC = decltype(kc)::value;                       // compile-time kt in the peeled steps, -1 in the loop
+    if constexpr (KC == 0) {
+      wait_keep_and_barrier<PER_STAGE + NB>();
+      LTXK_STAMP(7);
+      issue_gate();
+      LTXK_STAMP(1);
+    } else if constexpr (KC == 1) {
+      wait_keep_and_barrier<PER_STAGE + NB + NX2>();
+    } else if constexpr (HAS_RES && KC >= 3 && KC < 3 + TT) {
+      wait_keep_and_barrier<PER_STAGE + 4>();
+    } else {
+      wait_keep_and_barrier<PER_STAGE>();
+    }
+    if constexpr (HAS_RES && KC >= 2 && KC < 2 + TT) load_res_band(IntC<(KC >= 2 ? KC - 2 : 0)>{});
+    if (kt == 8) LTXK_STAMP(2);
+    int s2 = s + 2;
+    s2 = s2 >= 3 ? s2 - 3 : s2;
+    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
+    if constexpr (TT >= 2) {
+      pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+    } else {
+      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+    }
+    s = s + 1 == 3 ? 0 : s + 1;
+  };
+  auto kloop = [&](auto& pipe) __attribute__((always_inline)) {
+    if constexpr (TT >= 2) pipe.init();
+    [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+      ((I < nk ? kstep(pipe, I, IntC<I>{}) : (void)0), ...);
+    }(std::make_integer_sequence<int, PEEL>{});
+    for (int kt = PEEL; kt < nk; ++kt) kstep(pipe, kt, IntC<-1>{});
+    if constexpr (TT >= 2) pipe.finish(acc);
+  };
+  if constexpr (TT >= 2) {
 #if LTXK_STAGGER
     if (wave >= 4) {                  // SIMD partners of waves 0-3 run half a K-step out of phase
       MmaPipe<TT, 4, TRANS, TT> pipe;
@@ -136,17 +252,36 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       kloop(pipe);
     }
   } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      wait_stage_and_barrier(PER_STAGE);
-      int s2 = s + 2;
-      s2 = s2 >= 3 ? s2 - 3 : s2;
-      const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;
-      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc,
-                                        [&](int i) { issue_piece(i, kt2, s2); });
-      s = s + 1 == 3 ? 0 : s + 1;
-    }
+    int dummy = 0;
+    kloop(dummy);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Every prefetched value is "used" here, whatever the epilogue does with it: a load whose value is dead (the bias under
+  // EPI_SCALE_RES, which overwrites the biased value) is otherwise deleted - four loads fewer than the first waits allow
+  // in flight, i.e. a LoRA merge that raced its first stage.
+  if constexpr (TRANS) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre_t[nt]));
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre[nt]));
+  }
+  if constexpr (HAS_GATE) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(gpre[tt][nt]));
+  }
+  if constexpr (HAS_RES) {
+    if (nk < 2 + TT) {                 // short K: the bands whose step never ran
+      if (nk <= 2) load_res_band(IntC<0>{});
+      if (nk <= 3) load_res_band(IntC<1>{});
+      if (nk <= 4) load_res_band(IntC<2>{});
+      if (nk <= 5) load_res_band(IntC<3>{});
+      if (nk <= 6) load_res_band(IntC<4>{});
+    }
+  }
+  LTXK_STAMP(3);
 
   // ---- epilogue ----
   if constexpr (!TRANS) {
@@ -160,8 +295,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     for (int tt = 0; tt < TT; ++tt) {
       const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
       if (m >= p.M) continue;
-      int grow = 0;
-      if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) grow = p.gate_row ? p.gate_row[m] : 0;
       float ss = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -169,7 +302,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
         if (n >= p.N) continue;
         float y[4];
         if (p.bias) {
-          const bf16x4 b = *(const bf16x4*)(p.bias + n);
+          const bf16x4 b = bpre[nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
         } else {
@@ -183,7 +316,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
         } else if constexpr (EPI == LTXK_EPI_BIAS_GATE_RES) {
-          const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)grow * p.gate_stride + n);
+          const bf16x4 g = gpre[tt][nt];
           const bf16x4 r = rres[tt][nt];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
@@ -239,7 +372,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
       if (n >= p.N) continue;
-      const float b = p.bias ? (float)p.bias[n] : 0.f;
+      const float b = p.bias ? (float)bpre_t[nt] : 0.f;
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         const int m = m0 + wm * TT * 16 + tt * 16 + tq;
@@ -272,6 +405,7 @@ template <int TT, int EPI, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   using G = GemmGeom<TT, 4>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  LTXK_STAMP(4);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -286,6 +420,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
     if (n0 < p.n_split) gemm_tile<TT, EPI, false>(p, smem, m0, n0, wave, lane);
     else gemm_tile<TT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
   }
+#ifdef LTXK_DIAG
+  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LTXK_STAMP(5);
+  if (ltxk_gemm_stamps && threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    ltxk_gemm_stamps[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 template <int TT, int EPI, int MODE>

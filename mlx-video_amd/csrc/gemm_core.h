@@ -67,6 +67,12 @@ __device__ __forceinline__ void map_tile(int bid, int RT, int CT, int& rt, int& 
 
 // Wait until this wave's loads of the current K-step have landed, leaving `keep` younger
 // LDS-DMA instructions (the next K-step's) in flight, then rendezvous.
+template <int KEEP>
+__device__ __forceinline__ void wait_keep_and_barrier() {
+  static_assert(KEEP >= 0 && KEEP <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+}
+
 __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
   switch (keep) {
     case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
