@@ -1,11 +1,24 @@
-"""Measured-error ledger of the GPU parity tests.  Every stage-level comparison against the oracle goes through
-``check(name, measured, bound)``: it asserts ``measured <= bound`` and records both; at session end the ledger is
-written to ``gpurun_out/parity_measured.json`` (scratch on the GPU box; the copy judged is ``profiles/r02_parity.json``).
-Bounds are set to <= 2x the value measured on MI355X (rounded up to 2 significant digits), see that file."""
+"""Measured-error ledger of the GPU parity tests.  Every comparison against the oracle goes through
+``check(name, measured, bound)``.  Two limits apply, and the tighter one is enforced:
+
+* ``bound`` - the tolerance stated in the test (the documented tolerance of that stage);
+* the PIN of that check in ``tests/golden/parity_pins.json`` - 2x the value measured on MI355X when the pins were last
+  regenerated (``scripts/make_parity_pins.py`` from a ledger; floor 2e-4 for ulp-level metrics that measure ~1e-6 and
+  1.0 for the uint8 differences).  The kernels are deterministic and the inputs are seeded on the CPU, so a check
+  measures the same value on every MI355X; a kernel change that moves an error by more than 2x fails here even when
+  it stays inside the stated tolerance.
+
+At session end the ledger is written to ``gpurun_out/parity_measured.json`` (scratch on the GPU box; the copy judged is
+``profiles/r02_parity.json``)."""
 import json
 import os
 
 LEDGER = {}
+_PINS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_pins.json")
+try:
+    PINS = json.load(open(_PINS_PATH))["pins"] if os.environ.get("LTXK_PARITY_PINS", "1") != "0" else {}
+except (OSError, ValueError, KeyError):
+    PINS = {}
 
 
 def rel_l2(a, b) -> float:
@@ -15,10 +28,15 @@ def rel_l2(a, b) -> float:
 
 def check(name: str, measured: float, bound: float, note: str = "") -> float:
     measured = float(measured)
-    LEDGER[name] = {"measured": measured, "bound": float(bound), "ratio_bound_over_measured": (bound / measured) if measured > 0 else None}
+    pin = PINS.get(name)
+    eff = min(float(bound), float(pin)) if pin is not None else float(bound)
+    LEDGER[name] = {"measured": measured, "bound": eff, "stated_tolerance": float(bound), "pinned": pin is not None,
+                    "ratio_bound_over_measured": (eff / measured) if measured > 0 else None}
     if note:
         LEDGER[name]["note"] = note
-    assert measured <= bound, f"{name}: measured {measured:.3e} exceeds the stated bound {bound:.3e}"
+    assert measured <= eff, (f"{name}: measured {measured:.3e} exceeds " +
+                             (f"its pin {eff:.3e} (2x the value last measured; stated tolerance {bound:.3e})" if eff < bound
+                              else f"the stated tolerance {bound:.3e}"))
     return measured
 
 
