@@ -220,8 +220,9 @@ class _StepGraph:
             with torch.cuda.stream(side):
                 self._step()                              # real step 0, eager (device step counter 0 -> 1)
             torch.cuda.current_stream().wait_stream(side)
+            # thread_local: a process-group watchdog thread (RCCL, N > 1) polling its events must not invalidate the capture
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._step()
             start = 1
         for _ in range(start, nst):

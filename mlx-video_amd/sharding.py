@@ -156,10 +156,10 @@ class _ShardGraphs:
             self._tail()
             torch.cuda.synchronize()
             self.g_fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fwd):
+            with torch.cuda.graph(self.g_fwd, capture_error_mode="thread_local"):
                 self.v_local = self._fwd()                # static output tensor of the captured forward
             self.g_tail = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_tail):
+            with torch.cuda.graph(self.g_tail, capture_error_mode="thread_local"):
                 self._tail()
             start = 1
         for _ in range(start, nst):
