@@ -218,11 +218,11 @@ class LTXModel:
             out[k] = value
         return out
 
-    @classmethod
-    def random_init(cls, config: LTXModelConfig, device, seed: int = 1234) -> "LTXModel":
+    @staticmethod
+    def random_weights(config: LTXModelConfig, device, seed: int = 1234) -> Dict[str, torch.Tensor]:
         """Random weights of the exact architecture, generated on the device (synthetic bench;
         SURVEY.md §8d): Linear N(0,0.02^2), biases 0.01*N(0,1), tables N(0,0.02^2),
-        q/k-norm weights 1+0.1*N(0,1)."""
+        q/k-norm weights 1+0.1*N(0,1).  Module-name keys (what ``sanitize`` produces)."""
         g = torch.Generator(device=device).manual_seed(seed)
         D, FF = config.inner_dim, config.inner_dim * 4
         W: Dict[str, torch.Tensor] = {}
@@ -252,7 +252,11 @@ class LTXModel:
             lin(f"{pre}.ff.proj_in", FF, D)
             lin(f"{pre}.ff.proj_out", D, FF)
             W[f"{pre}.scale_shift_table"] = rn(6, D, std=0.02)
-        return cls(config, W)
+        return W
+
+    @classmethod
+    def random_init(cls, config: LTXModelConfig, device, seed: int = 1234) -> "LTXModel":
+        return cls(config, cls.random_weights(config, device, seed))
 
     # ------------------------------------------------------------------ forward
     def _prepare_context(self, context: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -14,7 +14,25 @@ from mlx_video_amd.weights import random_upsampler_weights
 dev = torch.device("cuda:0")
 BF = torch.bfloat16
 layers = int(os.environ.get("LAYERS", "48"))
-tr = LTXModel.random_init(LTXModelConfig(num_layers=layers), dev)
+cfg = LTXModelConfig(num_layers=layers)
+Wt = LTXModel.random_weights(cfg, dev)
+tr = LTXModel(cfg, Wt)
+
+
+def lora_file(path, rank, seed):
+    """A synthetic rank-`rank` LoRA over every attention projection of every block (PyTorch LTX-2 key naming, lora.py:18-33)."""
+    from safetensors.torch import save_file
+    gl = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i in range(layers):
+        for raw in ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn1.to_out.0", "attn2.to_q", "attn2.to_k", "attn2.to_v", "attn2.to_out.0"):
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_A.weight"] = (torch.randn(rank, 4096, generator=gl) * 0.02).to(BF)
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_B.weight"] = (torch.randn(4096, rank, generator=gl) * 0.02).to(BF)
+    save_file(sd, path)
+    return path
+
+
+lora64 = lora_file("/tmp/ltxk_synth_lora64.safetensors", 64, 5)
 dec = LTX2VideoDecoder(random_decoder_weights(dev))
 ups = LatentUpsampler(random_upsampler_weights(dev))
 g = torch.Generator(device=dev).manual_seed(1)
@@ -48,14 +66,16 @@ runs = [
     ("config1 dev 128x128x9 1 step", dict(pipeline=PipelineType.DEV, height=128, width=128, num_frames=9, num_inference_steps=1)),
     ("config2 dev 512x512x33 40 steps CFG4", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=33, num_inference_steps=40)),
     ("config4 (one seed) dev 512x512x97 40 steps CFG4, temporal-tiled decode", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=97, num_inference_steps=40, tiling="temporal")),
-    ("config3 distilled 768x768x65 two-stage", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3)),
-    ("config5 ic_lora 768x768x65 video-cond", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+    ("config3 distilled 768x768x65 two-stage + 2x upsampler, distilled LoRA (rank 64) merged into stage 2", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 distilled_loras=[(lora64, 0.8)])),
+    ("config5 ic_lora 768x768x65 video-cond, merged LoRA (rank 64)", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 loras=[(lora64, 1.0)],
                                                  video_conditionings=[((torch.rand((1, 3, 65, 768, 768), generator=g, device=dev) * 2 - 1).to(BF), 0, 1.0)])),
 ]
 for name, kw in runs:
     pj = f"/tmp/prof_{abs(hash(name))}.json"
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    fr = generate_video(prompt="x", transformer=tr, vae_decoder=dec, vae_encoder=enc, upsampler=ups, prompt_embeds=emb,
+    fr = generate_video(prompt="x", transformer=tr, transformer_weights=Wt, transformer_config=cfg, vae_decoder=dec, vae_encoder=enc, upsampler=ups, prompt_embeds=emb,
                         negative_prompt_embeds=neg, cfg_scale=4.0, compile_step=True, cfg_batch=True, device=dev, seed=7,
                         profile_json_path=pj, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
