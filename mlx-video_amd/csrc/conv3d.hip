@@ -10,6 +10,7 @@
 //   M = B*D*H*W voxels (channels-last rows), N = Cout, K = 27*Cin walked tap-major in 64-wide
 //   steps; same 3-stage LDS ring / MFMA loop as the Linear GEMM (gemm_core.h).
 #include "gemm_core.h"
+#include <utility>
 
 namespace ltxk {
 
@@ -126,22 +127,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     }
   };
 
-  // residual values of this tile: requested now, they arrive under the main loop (see gemm.hip)
+  // Epilogue operands are prefetched under the main loop exactly as in gemm.hip (which see for the why and for the
+  // compiler traps): the bias behind the first two stages' DMA, the residual tile in 16-row bands during the peeled
+  // K-steps 2 .. 1+TT; counted vmcnt waits leave them in flight.
   constexpr bool HAS_RES = RES && !SPLIT;
-  bf16x4 rres[HAS_RES ? TT : 1][4];
-  if constexpr (HAS_RES) {
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) {
+  constexpr int NB = SPLIT ? 0 : 4;
+  bf16x4 rres[HAS_RES ? TT : 1][4], bpre[4];
+  auto load_res_band = [&](auto tt_c) __attribute__((always_inline)) {
+    constexpr int tt = decltype(tt_c)::value;
+    if constexpr (HAS_RES && tt < TT) {
       int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
       m = m < p.M ? m : p.M - 1;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         int n = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
         n = n < p.Cout ? n : p.Cout - 4;
-        rres[tt][nt] = *(const bf16x4*)(p.resid + (size_t)m * p.Cout + n);
+        rres[tt][nt] = *opaque_gptr<bf16x4>((const bf16x4*)(p.resid + (size_t)m * p.Cout + n));
       }
     }
-  }
+  };
 
   f32x4 acc[TT][4];
 #pragma unroll
@@ -165,11 +169,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   }
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, kbeg + 1 < nk ? kbeg + 1 : kbeg, pcb, 1);
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      int n = n0 + wn * 64 + nt * 16 + (lane >> 4) * 4;
+      n = n < p.Cout ? n : p.Cout - 4;
+      bpre[nt] = *opaque_gptr<bf16x4>((const bf16x4*)(p.bias + n));
+    }
+  }
   int s = 0;
   MmaPipe<TT, WN, false> pipe;
   pipe.init();
-  for (int kt = kbeg; kt < nk; ++kt) {
-    wait_stage_and_barrier(PER_STAGE);
+  constexpr int PEEL = HAS_RES ? 3 + TT : 2;
+  auto kstep = [&](int kt, auto kc) __attribute__((always_inline)) {
+    constexpr int KC = decltype(kc)::value;                 // K-step index relative to kbeg in the peeled steps, -1 in the loop
+    if constexpr (KC == 0 || KC == 1) wait_keep_and_barrier<PER_STAGE + NB>();
+    else if constexpr (HAS_RES && KC >= 3 && KC < 3 + TT) wait_keep_and_barrier<PER_STAGE + 4>();
+    else wait_keep_and_barrier<PER_STAGE>();
+    if constexpr (HAS_RES && KC >= 2 && KC < 2 + TT) load_res_band(IntC<(KC >= 2 ? KC - 2 : 0)>{});
     int s2 = s + 2;
     s2 = s2 >= 3 ? s2 - 3 : s2;
     // advance the prefetch stream to K-step kt+2 (held at the last K-step in the tail: harmless re-load)
@@ -183,9 +200,27 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     const int cb = pcb;
     pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, cb, s2); });
     s = s + 1 == 3 ? 0 : s + 1;
-  }
+  };
+  [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
+    ((kbeg + I < nk ? kstep(kbeg + I, IntC<I>{}) : (void)0), ...);
+  }(std::make_integer_sequence<int, PEEL>{});
+  for (int kt = kbeg + PEEL; kt < nk; ++kt) kstep(kt, IntC<-1>{});
   pipe.finish(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre[nt]));      // never dead, never dropped (see gemm.hip)
+  }
+  if constexpr (HAS_RES) {
+    const int nsteps = nk - kbeg;
+    if (nsteps < 2 + TT) {             // short K: the bands whose step never ran
+      if (nsteps <= 2) load_res_band(IntC<0>{});
+      if (nsteps <= 3) load_res_band(IntC<1>{});
+      if (nsteps <= 4) load_res_band(IntC<2>{});
+      if (nsteps <= 5) load_res_band(IntC<3>{});
+      if (nsteps <= 6) load_res_band(IntC<4>{});
+    }
+  }
 
   // epilogue: acc[tt][nt][j]: voxel = lane&15, co = 4*(lane>>4) + j.  bf16 outputs go through a wave-private LDS
   // image (128-byte rows, chunks XOR-swizzled by row) and leave as whole 128-byte lines (see gemm.hip).
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
         *(f32x4*)(p.slab + ((size_t)slice * p.M + m) * p.Cout + n) = acc[tt][nt];
         continue;
       }
-      const bf16x4 b = *(const bf16x4*)(p.bias + n);
+      const bf16x4 b = bpre[nt];
       float y[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);

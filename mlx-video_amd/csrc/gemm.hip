@@ -29,20 +29,11 @@ extern "C" int ltxk_diag_set_gemm_stamps(void* p) {
 // whose value is only used when c holds gets unfolded by the optimiser into a load under `if (c)`: with bias == NULL a
 // LoRA merge then issued four loads fewer than its first wait allows in flight and raced its first stage.  The source
 // pointer is therefore made opaque first (an empty asm: no instruction, no wait), which leaves ONE unconditional load.
-// (The pointer comes back as an explicit global-address-space pointer: a generic one would turn the load into flat_load,
-// which hipcc waits for with vmcnt(0).)
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(1))) T* opaque_gptr(const T* p) {
-  uintptr_t u = (uintptr_t)p;
-  asm volatile("" : "+v"(u));
-  return (const __attribute__((address_space(1))) T*)u;
-}
 #define LTXK_VLOAD(T, ptr) (*opaque_gptr<T>((const T*)(ptr)))
 
 namespace ltxk {
 
 constexpr int GEMM_BN = 256;
-template <int V> struct IntC { static constexpr int value = V; };
 
 struct GemmParams {
   const bf16* A;

@@ -17,6 +17,20 @@
 
 namespace ltxk {
 
+template <int V> struct IntC { static constexpr int value = V; };
+
+// A global pointer the optimiser cannot see through (an empty asm: no instruction, no wait): `load(c ? a : dummy)` used
+// only when c holds otherwise gets unfolded into a load under `if (c)`, which breaks a counted-vmcnt prologue that
+// assumes a fixed number of loads per lane (gemm.hip).
+// (The pointer comes back as an explicit global-address-space pointer: a generic one would turn the load into flat_load,
+// which hipcc waits for with vmcnt(0).)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* opaque_gptr(const T* p) {
+  uintptr_t u = (uintptr_t)p;
+  asm volatile("" : "+v"(u));
+  return (const __attribute__((address_space(1))) T*)u;
+}
+
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_THREADS = 512;
 
