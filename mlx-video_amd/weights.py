@@ -144,7 +144,8 @@ def _vae_encoder_key(k: str) -> Optional[str]:
             kk = k[len(pre):]
     if kk is None:
         if "per_channel_statistics" in k:
-            kk = "per_channel_statistics." + ("mean" if "mean" in k.split(".")[-1] else "std")
+            last = k.split(".")[-1]                      # "mean-of-means" / "std-of-means" (also plain "mean" / "std")
+            kk = "per_channel_statistics." + ("std" if last.startswith("std") else "mean")
         else:
             return None
     kk = kk.replace(".conv.conv.", ".conv.").replace("conv_in.conv.", "conv_in.").replace("conv_out.conv.", "conv_out.")

@@ -192,6 +192,8 @@ def test_media_and_checkpoint_keymaps(tmp_path):
     assert w.shape == (2, 3, 3, 3, 3) and float(w[1, 2, 1, 0, 2]) == float(sd["vae.decoder.mid_block.resnets.1.conv1.conv.weight"][1, 2, 2, 1, 0])
     ew = weights.vae_encoder_weights(raw, "cpu")
     assert "down_blocks.0.res_blocks.1.conv1.weight" in ew and "per_channel_statistics.mean" in ew
+    # "std-of-means" contains the word "mean": it must still land on .std (it once overwrote .mean and left .std missing)
+    assert float(ew["per_channel_statistics.std"][0]) == 1.0 and float(ew["per_channel_statistics.mean"][0]) == 0.0
     assert weights.sniff_timestep_conditioning(tmp_path / "m.safetensors") is True
 
 

@@ -131,3 +131,71 @@ def test_pipeline_surface_and_errors(dev):
     pipe = TI2VidOneStagePipeline(height=100, width=120, num_frames=9, steps=1)
     fr = pipe("x", output_path=None, transformer=m["transformer"], vae_decoder=m["vae_decoder"], prompt_embeds=emb, device=dev)
     assert fr.shape == (9, 100, 120, 3)
+
+
+def _write_checkpoint(root, m, with_upsampler=True):
+    """A synthetic LTX-2 checkpoint DIRECTORY in the PyTorch naming / conv layout the reference converts from
+    (ltx.py:508-533, decoder.py:675-721, encoder.py:135-179): `model.diffusion_model.*`, `vae.decoder.*`, `vae.encoder.*`,
+    per-channel statistics under their PyTorch names, conv weights (O,I,D,H,W), `config` metadata."""
+    from safetensors.torch import save_file
+    sd = {}
+    for k, v in m["W"].items():
+        kk = k.replace(".to_out.", ".to_out.0.").replace(".ff.proj_in.", ".ff.net.0.proj.").replace(".ff.proj_out.", ".ff.net.2.")
+        kk = kk.replace(".linear1.", ".linear_1.").replace(".linear2.", ".linear_2.")
+        sd["model.diffusion_model." + kk] = v.contiguous()
+    sd["model.diffusion_model.audio_embeddings_connector.dummy"] = torch.zeros(4, dtype=BF)      # must be skipped (ltx.py:516-518)
+    for k, v in m["Wd"].items():
+        if k == "latents_mean":
+            sd["vae.per_channel_statistics.mean-of-means"] = v.contiguous()
+        elif k == "latents_std":
+            sd["vae.per_channel_statistics.std-of-means"] = v.contiguous()
+        else:
+            sd["vae.decoder." + k] = (v.permute(0, 4, 1, 2, 3) if v.ndim == 5 else v).contiguous()   # (O,D,H,W,I) -> (O,I,D,H,W)
+    for k, v in m["We"].items():
+        if k.startswith("per_channel_statistics"):
+            continue                                        # shared with the decoder's entries above in real checkpoints
+        sd["vae.encoder." + k] = (v.permute(0, 4, 1, 2, 3) if v.ndim == 5 else v).contiguous()
+    root.mkdir(parents=True, exist_ok=True)
+    save_file(sd, str(root / "ltx-2-synthetic.safetensors"), metadata={"config": json.dumps({"vae": {"timestep_conditioning": False}})})
+    if with_upsampler:
+        su = {}
+        for k, v in m["Wu"].items():
+            su[k] = (v.permute(0, 4, 1, 2, 3) if v.ndim == 5 else (v.permute(0, 3, 1, 2) if v.ndim == 4 else v)).contiguous()
+        save_file(su, str(root / "ltx-2-spatial-upscaler-x2.safetensors"))
+
+
+def test_model_repo_directory_end_to_end(dev, tmp_path):
+    """weights.load_pipeline_modules from a checkpoint directory (header scan, config inferred from shapes, tensors streamed to
+    the device one by one) must give the SAME frames as the modules built directly from the same tensors - dev I2V at
+    128x128x9 (needs transformer + decoder + encoder) and the distilled two-stage pipeline (needs the upsampler file)."""
+    from mlx_video_amd.generate import PipelineType, generate_video
+    from mlx_video_amd.weights import load_pipeline_modules, scan_header
+    m = _mods(dev)
+    # the encoder's statistics are the decoder's in a real checkpoint: make the direct modules agree with that
+    We = dict(m["We"])
+    We["per_channel_statistics.mean"], We["per_channel_statistics.std"] = m["Wd"]["latents_mean"], m["Wd"]["latents_std"]
+    from mlx_video_amd.video_vae import VideoEncoder
+    enc = VideoEncoder({k: v.to(dev) for k, v in We.items()}, encoder_blocks=m["blocks"])
+    repo = tmp_path / "repo"
+    _write_checkpoint(repo, m)
+    hdr = scan_header(repo / "ltx-2-synthetic.safetensors")
+    assert "__metadata__" in hdr and len(hdr) > 100
+    mods = load_pipeline_modules(str(repo), dev, need_encoder=True, need_upsampler=True)
+    tc = mods["transformer_config"]
+    assert (tc.num_layers, tc.num_attention_heads, tc.caption_channels, tc.in_channels) == (2, 4, 256, 128)
+    assert mods["vae_decoder"].timestep_conditioning is False and "upsampler" in mods and "vae_encoder" in mods
+    assert all(v.is_cuda and v.dtype == BF for v in mods["transformer_weights"].values())
+    g = torch.Generator().manual_seed(51)
+    pe_pos = torch.randn(1, 64, 256, generator=g).to(BF)
+    pe_neg = torch.randn(1, 64, 256, generator=g).to(BF)
+    img = (torch.rand(1, 3, 1, 128, 128, generator=g) * 2 - 1).to(BF)
+    common = dict(prompt="x", height=128, width=128, num_frames=9, prompt_embeds=pe_pos, negative_prompt_embeds=pe_neg,
+                  images=[(img, 0, 1.0)], compile_step=True, cfg_batch=True, device=dev, cfg_scale=4.0)
+    for pipe, extra in ((PipelineType.DEV, dict(num_inference_steps=2)), (PipelineType.DISTILLED, dict(stage1_steps=2, stage2_steps=1))):
+        a = generate_video(model_repo=str(repo), pipeline=pipe, noise_fn=_Noise(9, dev), **common, **extra)
+        b = generate_video(pipeline=pipe, transformer=m["transformer"], vae_decoder=m["vae_decoder"], vae_encoder=enc,
+                           upsampler=m["upsampler"], noise_fn=_Noise(9, dev), **common, **extra)
+        assert a.shape == b.shape == (9, 128, 128, 3)
+        assert np.array_equal(a, b), f"{pipe}: frames from the checkpoint directory differ from the directly built modules"
+    with pytest.raises(FileNotFoundError):
+        load_pipeline_modules(str(tmp_path / "nope"), dev)
