@@ -199,3 +199,55 @@ def test_model_repo_directory_end_to_end(dev, tmp_path):
         assert np.array_equal(a, b), f"{pipe}: frames from the checkpoint directory differ from the directly built modules"
     with pytest.raises(FileNotFoundError):
         load_pipeline_modules(str(tmp_path / "nope"), dev)
+
+
+def test_cli_ic_lora_from_paths(dev, tmp_path):
+    """`python -m mlx_video_amd.generate --pipeline ic_lora` with everything given as PATHS (generate.py:4346-4415, 4667-4698):
+    a checkpoint directory, an image file, a directory of conditioning frames, a LoRA safetensors file, prompt embeddings as
+    .npy; the frames it writes equal generate_video() called with the loaded modules and the same path arguments."""
+    from PIL import Image
+    from safetensors.torch import save_file
+    from mlx_video_amd import generate as G
+    from mlx_video_amd.weights import load_pipeline_modules
+    m = _mods(dev)
+    repo = tmp_path / "repo"
+    _write_checkpoint(repo, m)
+    rng = np.random.default_rng(3)
+    Image.fromarray(rng.integers(0, 255, (128, 128, 3), dtype=np.uint8)).save(tmp_path / "first.png")
+    fdir = tmp_path / "guide"
+    fdir.mkdir()
+    for i in range(9):
+        Image.fromarray(rng.integers(0, 255, (64, 64, 3), dtype=np.uint8)).save(fdir / f"f{i:03d}.png")
+    g = torch.Generator().manual_seed(61)
+    sd = {}
+    for i in range(2):
+        for raw in ("attn1.to_q", "attn1.to_out.0", "ff.net.0.proj"):
+            o, n_in = m["W"][f"transformer_blocks.{i}." + raw.replace("to_out.0", "to_out").replace("ff.net.0.proj", "ff.proj_in") + ".weight"].shape
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_A.weight"] = (torch.randn(8, n_in, generator=g) * 0.1).to(BF)
+            sd[f"diffusion_model.transformer_blocks.{i}.{raw}.lora_B.weight"] = (torch.randn(o, 8, generator=g) * 0.1).to(BF)
+    save_file(sd, str(tmp_path / "ic.safetensors"))
+    np.save(tmp_path / "pe.npy", torch.randn(1, 64, 256, generator=g).numpy().astype(np.float32))
+    out = tmp_path / "cli.npy"
+    pj = tmp_path / "cli.json"
+    G.main(["--pipeline", "ic_lora", "--model-repo", str(repo), "--height", "128", "--width", "128", "--num-frames", "9",
+            "--stage1-steps", "2", "--stage2-steps", "1", "--seed", "11", "--image", str(tmp_path / "first.png"), "0", "1.0",
+            "--video-conditioning", str(fdir), "0", "0.9", "--lora", str(tmp_path / "ic.safetensors"), "0.8",
+            "--prompt-embeds", str(tmp_path / "pe.npy"), "--output-path", str(out), "--profile-json", str(pj), "--tiling", "none"])
+    frames = np.load(out)
+    assert frames.shape == (9, 128, 128, 3) and frames.dtype == np.uint8
+    prof = json.loads(pj.read_text())
+    assert prof["pipeline"] == "ic_lora" and {"cond_encode", "stage1_denoise", "upsample", "stage2_denoise", "vae_decode"} <= set(prof["phases_s"])
+    mods = load_pipeline_modules(str(repo), dev, need_encoder=True, need_upsampler=True, build_transformer=False)
+    ref = G.generate_video(prompt="", pipeline=G.PipelineType.IC_LORA, height=128, width=128, num_frames=9, stage1_steps=2, stage2_steps=1,
+                           seed=11, images=[(str(tmp_path / "first.png"), 0, 1.0)], video_conditionings=[(str(fdir), 0, 0.9)],
+                           loras=[(str(tmp_path / "ic.safetensors"), 0.8)], transformer_weights=mods["transformer_weights"],
+                           transformer_config=mods["transformer_config"], vae_decoder=mods["vae_decoder"], vae_encoder=mods["vae_encoder"],
+                           upsampler=mods["upsampler"], prompt_embeds=torch.from_numpy(np.load(tmp_path / "pe.npy")), device=dev, tiling="none")
+    assert np.array_equal(frames, ref)
+    # and the LoRA is really applied: without it the frames differ
+    base = G.generate_video(prompt="", pipeline=G.PipelineType.IC_LORA, height=128, width=128, num_frames=9, stage1_steps=2, stage2_steps=1,
+                            seed=11, images=[(str(tmp_path / "first.png"), 0, 1.0)], video_conditionings=[(str(fdir), 0, 0.9)],
+                            transformer_weights=mods["transformer_weights"], transformer_config=mods["transformer_config"],
+                            vae_decoder=mods["vae_decoder"], vae_encoder=mods["vae_encoder"], upsampler=mods["upsampler"],
+                            prompt_embeds=torch.from_numpy(np.load(tmp_path / "pe.npy")), device=dev, tiling="none")
+    assert not np.array_equal(frames, base)
