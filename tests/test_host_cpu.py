@@ -259,3 +259,16 @@ def test_trapezoid_mask_known_properties():
         assert bool((m[1:9] >= m[:8]).all()) and bool((m[-8:] <= m[-9:-1]).all())        # ramps monotonic
         assert float(fn(32, 8, 0, True)[0]) == 0.0                                          # temporal: starts from 0
         assert float(fn(32, 8, 0, False)[0]) > 0.0                                          # spatial: starts above 0
+
+
+def test_bench_flop_accounting_matches_survey_table():
+    """bench.dit_forward_flops restates SURVEY.md §8d's formula: the per-forward totals of its table must come out
+    (TFLOP/forward at N = 32, 1280, 1296, 5184, 3328), and the "executed" variant only drops the per-token AdaLN MLPs."""
+    import bench
+    for n, tflop in ((32, 4.12), (1280, 34.85), (1296, 35.26), (5184, 146.81), (3328, 90.59)):
+        assert abs(bench.dit_forward_flops(n) / 1e12 - tflop) < 0.006 * tflop, n
+    full, executed = bench.dit_forward_flops(1280, B=2), bench.dit_forward_flops(1280, B=2, U=1)
+    D = 4096
+    assert abs((full - executed) - (2 * 2 * 1280 - 2) * (256 * D + D * D + 6 * D * D)) < 1e6
+    assert 69.5e12 < full < 69.9e12                       # the 69.7 TFLOP/step the bench line quotes
+    assert len(bench.source_sha()) == 16
