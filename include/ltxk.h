@@ -248,6 +248,17 @@ typedef struct ltxk_conv3d_args {
    * upsampler's nn.Conv2d applied frame by frame, upsampler.py:64-99): only the centre temporal tap exists,
    * K = 9*Cin instead of 27*Cin.                                                                        */
   int32_t taps_d;
+  /* Optional fused PixelNorm (+ AdaLN modulation) + SiLU of the OUTPUT row (decoder.py:136-180: the pixel_norm / scale /
+   * shift / SiLU that follows every conv of a res block; utils.py:477-483):
+   *   act_out[v,:] = silu?( modulate?( pixel_norm(y[v,:], act_eps) ) ),  y = this conv's bf16 output row (bias, residual),
+   * with the rounding points of ltxk_pixelnorm_act.  Needs Cout == 128 or 256 (the tile then holds whole voxel rows; the
+   * row statistic is reduced inside the tile).  act_out == NULL: off.  `out` may be NULL when act_out is set (a conv whose
+   * raw output nothing else reads).  act_scale / act_shift: (B,Cout) bf16 or both NULL; act_rows_per_batch = D*H*W. */
+  void* act_out;
+  const void* act_scale;
+  const void* act_shift;
+  float act_eps;
+  int32_t act_silu;
 } ltxk_conv3d_args;
 
 /* nn.Conv3d 3x3x3 stride 1 inside CausalConv3d (convolution.py:78-222) as implicit GEMM.   */

@@ -43,6 +43,7 @@ class Conv3dArgs(Structure):
         ("Cin", c_int32), ("Cout", c_int32),
         ("causal", c_int32), ("pad_mode", c_int32),
         ("workspace", c_void_p), ("workspace_bytes", c_int64), ("taps_d", c_int32),
+        ("act_out", c_void_p), ("act_scale", c_void_p), ("act_shift", c_void_p), ("act_eps", c_float), ("act_silu", c_int32),
     ]
 
 

@@ -22,6 +22,8 @@ struct ConvParams {
   float* slab;          // split-K: fp32 partial slabs [S][M][Cout] (plain stores, summed in slice order)
   int S, kper;          // K slices per tile, K-steps per slice
   int ntaps, kd0;       // 27 taps from kd=0, or 9 taps at kd0=1 (per-frame 3x3 kernel)
+  // fused PixelNorm (+ modulation) + SiLU of the output row (needs Cout == BN: the tile holds whole rows)
+  bf16* act_out; const bf16* act_scale; const bf16* act_shift; float act_eps; int act_silu; int rows_per_batch;
 };
 
 template <int TT, int WN, bool RES, bool SPLIT>
@@ -226,10 +228,44 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   // image (128-byte rows, chunks XOR-swizzled by row) and leave as whole 128-byte lines (see gemm.hip).
   const int nq = (lane >> 4) * 4;
   const bool wide = !SPLIT && (p.Cout & 7) == 0;
+  const bool do_act = !SPLIT && p.act_out != nullptr, do_out = p.out != nullptr;
   char* stg = smem + wave * (TT * 16 * 128);
   if (wide) __syncthreads();
+  // y of (tt, nt): the conv's bf16 output values (bias, residual), as floats
+  auto out_vals = [&](int tt, int nt, float (&y)[4]) __attribute__((always_inline)) {
+    const bf16x4 b = bpre[nt];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
+    if constexpr (HAS_RES) {
+      const bf16x4 r = rres[tt][nt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = rbf(y[j] + (float)r[j]);
+    }
+  };
+  auto stage_or_store = [&](bf16* dst, int tt, int nt, int m, int n, bf16x4 o) __attribute__((always_inline)) {
+    if (wide) {
+      const int r = tt * 16 + (lane & 15), cg = lane >> 4;
+      *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
+    } else {
+      *(bf16x4*)(dst + (size_t)m * p.Cout + n) = o;
+    }
+  };
+  auto flush_lines = [&](bf16* dst) __attribute__((always_inline)) {
+    if (!wide) return;
+    const int c = lane & 7;
+    const int n = n0 + wn * 64 + c * 8;
+#pragma unroll
+    for (int i = 0; i < TT * 2; ++i) {
+      const int r = i * 8 + (lane >> 3);
+      const int m = m0 + wm * TT * 16 + r;
+      const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+      if (m < p.M && n < p.Cout) *(bf16x8*)(dst + (size_t)m * p.Cout + n) = v;
+    }
+  };
+  float rowsq[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    rowsq[tt] = 0.f;
     const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
@@ -240,36 +276,68 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
         *(f32x4*)(p.slab + ((size_t)slice * p.M + m) * p.Cout + n) = acc[tt][nt];
         continue;
       }
-      const bf16x4 b = bpre[nt];
       float y[4];
+      out_vals(tt, nt, y);
+      if (do_act) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
-      if constexpr (HAS_RES) {
-        const bf16x4 r = rres[tt][nt];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = y[j] + (float)r[j];
+        for (int j = 0; j < 4; ++j) rowsq[tt] += rbf(y[j] * y[j]);          // PixelNorm's mean of squares, squares rounded as in ltxk_pixelnorm_act
       }
-      bf16x4 o;
+      if (do_out) {
+        bf16x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
-      if (wide) {
-        const int r = tt * 16 + (lane & 15), cg = lane >> 4;
-        *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
-      } else {
-        *(bf16x4*)(p.out + (size_t)m * p.Cout + n) = o;
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+        stage_or_store(p.out, tt, nt, m, n, o);
       }
     }
   }
-  if (wide) {
-    const int c = lane & 7;
-    const int n = n0 + wn * 64 + c * 8;
+  if (do_out) flush_lines(p.out);
+  if (do_act) {
+    // Row statistic: the lane's 16 values -> the wave's 64 columns (4 lane groups) -> the tile's Cout columns (WN waves,
+    // through LDS in wave order: deterministic).  The tile spans every channel (Cout == BN, checked on the host).
+    float* part = (float*)(smem + 8 * (TT * 16 * 128));                       // behind the 8 staging images
 #pragma unroll
-    for (int i = 0; i < TT * 2; ++i) {
-      const int r = i * 8 + (lane >> 3);
-      const int m = m0 + wm * TT * 16 + r;
-      const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
-      if (m < p.M && n < p.Cout) *(bf16x8*)(p.out + (size_t)m * p.Cout + n) = v;
+    for (int tt = 0; tt < TT; ++tt) {
+      float v = rowsq[tt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 16) part[((wm * TT + tt) * 16 + lane) * WN + wn] = v;
     }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) tot += part[((wm * TT + tt) * 16 + (lane & 15)) * WN + w];
+      const float mean = rbf(tot / (float)p.Cout);
+      const float sd = rbf(sqrtf(rbf(mean + p.act_eps)));
+      const float rsd = 1.0f / sd;
+      if (m >= p.M) continue;
+      const size_t mrow = p.act_scale ? (size_t)(m / p.rows_per_batch) * p.Cout : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + nq;
+        if (n >= p.Cout) continue;
+        float y[4];
+        out_vals(tt, nt, y);
+        bf16x4 sc, sh;
+        if (p.act_scale) {
+          sc = *(const bf16x4*)(p.act_scale + mrow + n);
+          sh = *(const bf16x4*)(p.act_shift + mrow + n);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float q0 = y[j] * rsd;                                          // x / sd: reciprocal + one Newton step (see ltxk_pixelnorm_act)
+          float t = rbf(__builtin_fmaf(__builtin_fmaf(-q0, sd, y[j]), rsd, q0));
+          if (p.act_scale) t = rbf(rbf(t * rbf(1.0f + (float)sc[j])) + (float)sh[j]);
+          if (p.act_silu) t = silu_f(t);
+          o[j] = (bf16)t;
+        }
+        stage_or_store(p.act_out, tt, nt, m, n, o);
+      }
+    }
+    flush_lines(p.act_out);
   }
 }
 
@@ -358,7 +426,7 @@ static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspac
 extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   using namespace ltxk;
   LTXK_CHECK_ARG(a != nullptr, "ltxk_conv3d_k3_bf16: null args");
-  LTXK_CHECK_ARG(a->x && a->w && a->bias && a->out && a->zero_page, "ltxk_conv3d_k3_bf16: null x/w/bias/out/zero_page");
+  LTXK_CHECK_ARG(a->x && a->w && a->bias && (a->out || a->act_out) && a->zero_page, "ltxk_conv3d_k3_bf16: null x/w/bias/out/zero_page");
   LTXK_CHECK_ARG(a->B > 0 && a->D > 0 && a->H >= 2 && a->W >= 2, "ltxk_conv3d_k3_bf16: bad volume %dx%dx%dx%d", a->B, a->D, a->H, a->W);
   LTXK_CHECK_ARG(a->Cin % 64 == 0 && a->Cin > 0, "ltxk_conv3d_k3_bf16: Cin=%d must be a multiple of 64 (pad channels with zeros)", a->Cin);
   LTXK_CHECK_ARG(a->Cout % 8 == 0 && a->Cout > 0, "ltxk_conv3d_k3_bf16: Cout=%d must be a multiple of 8", a->Cout);
@@ -373,10 +441,17 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.causal = a->causal; p.pad_mode = a->pad_mode; p.M = (int)M; p.cpb = a->Cin / 64; p.RT = p.CT = 0;
   LTXK_CHECK_ARG(a->taps_d == 0 || a->taps_d == 3 || a->taps_d == 1, "ltxk_conv3d_k3_bf16: taps_d must be 3 (or 0) or 1, got %d", a->taps_d);
   p.ntaps = a->taps_d == 1 ? 9 : 27; p.kd0 = a->taps_d == 1 ? 1 : 0;
+  p.act_out = (bf16*)a->act_out; p.act_scale = (const bf16*)a->act_scale; p.act_shift = (const bf16*)a->act_shift;
+  p.act_eps = a->act_eps; p.act_silu = a->act_silu; p.rows_per_batch = a->D * a->H * a->W;
+  if (a->act_out) {
+    LTXK_CHECK_ARG(a->Cout == 128 || a->Cout == 256, "ltxk_conv3d_k3_bf16: the fused norm/activation output needs Cout == 128 or 256 (got %d)", a->Cout);
+    LTXK_CHECK_ARG((a->act_scale == nullptr) == (a->act_shift == nullptr), "ltxk_conv3d_k3_bf16: act_scale and act_shift must both be set or both NULL");
+    LTXK_CHECK_ARG(((uintptr_t)a->act_out & 15) == 0 && (((uintptr_t)a->act_scale | (uintptr_t)a->act_shift) & 7) == 0, "ltxk_conv3d_k3_bf16: misaligned act_* pointer");
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool res = a->resid != nullptr;
-  float* ws = (float*)a->workspace;
-  const size_t wsb = a->workspace ? (size_t)a->workspace_bytes : 0;
+  float* ws = a->act_out ? nullptr : (float*)a->workspace;          // the fused row statistic lives in the tile: no split-K
+  const size_t wsb = ws ? (size_t)a->workspace_bytes : 0;
   LTXK_CHECK_ARG(((uintptr_t)ws & 15) == 0, "ltxk_conv3d_k3_bf16: workspace must be 16-byte aligned");
   if (a->Cout <= 128) {       // 256x128 tile: no wasted MFMA columns on the 128-channel stage
     return res ? conv_launch<4, 2, true>(p, st, ws, wsb) : conv_launch<4, 2, false>(p, st, ws, wsb);

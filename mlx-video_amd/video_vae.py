@@ -11,6 +11,8 @@ padded copies), and the norm/activation kernels are one-row-per-voxel streams.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 import math
 from dataclasses import dataclass
@@ -57,15 +59,17 @@ def _zero_page(dev) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------ op shims
 def conv3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, causal: bool, pad_mode: int,
-           resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+           resid: Optional[torch.Tensor] = None, act: Optional[dict] = None, keep_out: bool = True):
     """x (B,D,H,W,Cin) bf16 channels-last; w (Cout,3,3,3,Cin), or (Cout,3,3,Cin) for a per-frame 3x3 kernel;
-    returns (B,D,H,W,Cout)."""
+    returns (B,D,H,W,Cout).  ``act`` = dict(eps, silu, scale, shift): the PixelNorm (+ modulation) + SiLU that follows
+    this conv is applied to its output rows in the epilogue (Cout 128 / 256) and returned as a second tensor:
+    ``(out, act_out)``; ``keep_out=False`` skips the raw output (``out`` is None) when nothing else reads it."""
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
     taps_d = 3 if w.dim() == 5 else 1
     if tuple(w.shape[1:]) != ((3, 3, 3, Cin) if taps_d == 3 else (3, 3, Cin)):
         raise ValueError(f"conv3d: weight {tuple(w.shape)} does not match Cin={Cin}")
-    out = torch.empty((B, D, H, W, Cout), dtype=BF16, device=x.device)
+    out = torch.empty((B, D, H, W, Cout), dtype=BF16, device=x.device) if (keep_out or act is None) else None
     a = Conv3dArgs()
     a.x, a.w, a.bias, a.out, a.resid = _p(x), _p(w), _p(b), _p(out), _p(resid)
     a.zero_page = _p(_zero_page(x.device))
@@ -73,11 +77,28 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, causal: bool, pad_
     a.causal, a.pad_mode, a.taps_d = int(causal), pad_mode, taps_d
     ws = _workspace(x.device)
     a.workspace, a.workspace_bytes = _p(ws), ws.numel() * 4
+    act_out = None
+    if act is not None:
+        act_out = torch.empty((B, D, H, W, Cout), dtype=BF16, device=x.device)
+        a.act_out, a.act_scale, a.act_shift = _p(act_out), _p(act.get("scale")), _p(act.get("shift"))
+        a.act_eps, a.act_silu = float(act["eps"]), int(bool(act.get("silu", True)))
     V = B * D * H * W
     ntap = 27 if taps_d == 3 else 9
     with ops._timed("conv3d_k3", 2.0 * ntap * Cin * Cout * V, 2.0 * V * (Cin + Cout) + 2.0 * ntap * Cin * Cout):
         check(_lib.load().ltxk_conv3d_k3_bf16(ctypes.byref(a), _stream()), "ltxk_conv3d_k3_bf16")
-    return out
+    return out if act is None else (out, act_out)
+
+
+def conv_act_fusable(Cout: int, voxels: int, force: bool = False) -> bool:
+    """The conv epilogue can carry the following PixelNorm + SiLU when its tile holds whole rows (Cout 128 / 256) and the
+    launch would not be split along K anyway (more than 128 tiles: the small 1024 / 512-channel volumes keep split-K).
+    OFF by default (LTXK_VAE_FUSE_ACT=1 turns it on): measured on the 33x512x512 decode, same box, interleaved -
+    12.34 ms separate vs 12.47 ms fused: the normalisation's ~25 VALU per element cost the MFMA kernel's serial epilogue
+    0.77 ms, more than the 0.66 ms the HBM-bound PixelNorm launches took beside nothing (profiles/r02_vae_fusion_ab.log)."""
+    if (os.environ.get("LTXK_VAE_FUSE_ACT", "0") != "1" and not force) or Cout not in (128, 256):
+        return False
+    bm = 256 if Cout <= 128 else 160
+    return (voxels + bm - 1) // bm > 128
 
 
 def pixelnorm_act(x: torch.Tensor, eps: float, silu: bool, scale: Optional[torch.Tensor] = None,
@@ -371,6 +392,12 @@ class LTX2VideoDecoder:
                                                 _p(self.latents_mean), _p(self.latents_std), _p(xcl), B, C, S, _stream()),
               "ltxk_latent_denorm_cl")
         x = conv3d(xcl, W["conv_in.conv.weight"], W["conv_in.conv.bias"], causal, PAD_REFLECT)
+        sc = sh = None                          # modulation of the last PixelNorm (before conv_out)
+        if tc:
+            emb = self._time_embed(st, "last_time_embedder")
+            ada = ops.ada_combine(W["last_scale_shift_table"].reshape(1, 2, 128), emb, 1, B, 2, 128)[0]
+            sh, sc = ada[:, 0].contiguous(), ada[:, 1].contiguous()
+        h_final = None
         for bi in range(7):
             pre = f"up_blocks.{bi}"
             if bi % 2 == 0:
@@ -378,24 +405,44 @@ class LTX2VideoDecoder:
                 mods = None
                 if tc:
                     emb = self._time_embed(st, f"{pre}.time_embedder")                      # (B,4C)
-                for li in range(self.num_layers_per_block):
-                    rp = f"{pre}.res_blocks.{li}"
+                nl = self.num_layers_per_block
+                all_mods = []
+                for li in range(nl):
                     if tc:
-                        ada = ops.ada_combine(W[f"{rp}.scale_shift_table"].reshape(1, 4, c), emb, 1, B, 4, c)[0]   # (B,4,C)
-                        mods = [ada[:, i].contiguous() for i in range(4)]                    # shift1, scale1, shift2, scale2
-                    h = pixelnorm_act(x, 1e-8, True, mods[1] if tc else None, mods[0] if tc else None)
-                    h = conv3d(h, W[f"{rp}.conv1.conv.weight"], W[f"{rp}.conv1.conv.bias"], causal, PAD_REFLECT)
-                    h = pixelnorm_act(h, 1e-8, True, mods[3] if tc else None, mods[2] if tc else None)
-                    x = conv3d(h, W[f"{rp}.conv2.conv.weight"], W[f"{rp}.conv2.conv.bias"], causal, PAD_REFLECT, resid=x)
+                        ada = ops.ada_combine(W[f"{pre}.res_blocks.{li}.scale_shift_table"].reshape(1, 4, c), emb, 1, B, 4, c)[0]   # (B,4,C)
+                        all_mods.append([ada[:, i].contiguous() for i in range(4)])          # shift1, scale1, shift2, scale2
+                    else:
+                        all_mods.append([None] * 4)
+                # PixelNorm + SiLU ride in the epilogue of the conv that produces their input where the tile holds whole
+                # rows (128 / 256 channels): conv1 then writes ONLY its normalised output, conv2 writes the residual
+                # stream and, for the next block, its normalised copy.
+                fuse = conv_act_fusable(c, x.numel() // c)          # off by default: measured slower, see conv_act_fusable
+                h_next = None
+                for li in range(nl):
+                    rp = f"{pre}.res_blocks.{li}"
+                    mods = all_mods[li]
+                    h = h_next if h_next is not None else pixelnorm_act(x, 1e-8, True, mods[1], mods[0])
+                    h_next = None
+                    if fuse:
+                        _, h = conv3d(h, W[f"{rp}.conv1.conv.weight"], W[f"{rp}.conv1.conv.bias"], causal, PAD_REFLECT,
+                                      act=dict(eps=1e-8, silu=True, scale=mods[3], shift=mods[2]), keep_out=False)
+                        if li + 1 < nl:
+                            nm = all_mods[li + 1]
+                            x, h_next = conv3d(h, W[f"{rp}.conv2.conv.weight"], W[f"{rp}.conv2.conv.bias"], causal, PAD_REFLECT, resid=x,
+                                               act=dict(eps=1e-8, silu=True, scale=nm[1], shift=nm[0]))
+                        elif bi == 6:            # the decoder's last res block: its successor is the PixelNorm in front of conv_out
+                            x, h_final = conv3d(h, W[f"{rp}.conv2.conv.weight"], W[f"{rp}.conv2.conv.bias"], causal, PAD_REFLECT, resid=x,
+                                                act=dict(eps=1e-8, silu=True, scale=sc, shift=sh))
+                        else:
+                            x = conv3d(h, W[f"{rp}.conv2.conv.weight"], W[f"{rp}.conv2.conv.bias"], causal, PAD_REFLECT, resid=x)
+                    else:
+                        h = conv3d(h, W[f"{rp}.conv1.conv.weight"], W[f"{rp}.conv1.conv.bias"], causal, PAD_REFLECT)
+                        h = pixelnorm_act(h, 1e-8, True, mods[3], mods[2])
+                        x = conv3d(h, W[f"{rp}.conv2.conv.weight"], W[f"{rp}.conv2.conv.bias"], causal, PAD_REFLECT, resid=x)
             else:
                 cv = conv3d(x, W[f"{pre}.conv.weight"], W[f"{pre}.conv.bias"], causal, PAD_REFLECT)
                 x = d2s_add(cv, x)
-        sc = sh = None
-        if tc:
-            emb = self._time_embed(st, "last_time_embedder")
-            ada = ops.ada_combine(W["last_scale_shift_table"].reshape(1, 2, 128), emb, 1, B, 2, 128)[0]
-            sh, sc = ada[:, 0].contiguous(), ada[:, 1].contiguous()
-        x = pixelnorm_act(x, 1e-8, True, sc, sh)
+        x = h_final if h_final is not None else pixelnorm_act(x, 1e-8, True, sc, sh)
         y = conv3d(x, W["conv_out.conv.weight"], W["conv_out.conv.bias"], causal, PAD_REFLECT)
         _, Fo, Ho, Wo, _ = y.shape
         P = self.patch_size

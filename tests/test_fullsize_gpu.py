@@ -173,3 +173,27 @@ def test_denoise_fullsize_smoke(dev):
     finally:
         del os.environ["LTXK_FA_SPLIT"]
     assert torch.equal(a0, b0)
+
+
+@pytest.mark.parametrize("tc", [False, True])
+def test_vae_decode_with_fused_pixelnorm(dev, monkeypatch, tc):
+    """LTXK_VAE_FUSE_ACT=1 (PixelNorm + modulation + SiLU carried by the conv epilogues of the 256 / 128-channel stages,
+    off by default because it measured slower) decodes the same 33x512x512 video up to the association order of the
+    row statistic; also with timestep conditioning (per-batch modulation inside the fused epilogue)."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, random_decoder_weights
+    if tc:
+        from oracle import vae as OV
+        W = {k: v.to(dev) for k, v in OV.make_decoder_weights(seed=8, timestep_conditioning=True, layers_per_block=2).items()}
+    else:
+        W = random_decoder_weights(dev, layers=2)
+    dec = LTX2VideoDecoder(W, num_layers_per_block=2, timestep_conditioning=tc)
+    g = torch.Generator(device=dev).manual_seed(4)
+    lat = torch.randn((1, 128, 5, 16, 16), generator=g, device=dev).to(BF)
+    noise = torch.randn((1, 128, 5, 16, 16), generator=g, device=dev).to(BF) if tc else None
+    monkeypatch.setenv("LTXK_VAE_FUSE_ACT", "0")
+    a = dec(lat, noise=noise)
+    monkeypatch.setenv("LTXK_VAE_FUSE_ACT", "1")
+    b = dec(lat, noise=noise)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (1, 3, 33, 512, 512)
+    parity.auto(rel_l2(b.float(), a.float()), 5e-3)

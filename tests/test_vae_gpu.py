@@ -3,6 +3,8 @@ policy) on seeded inputs.  Index maps (patchify/unpatchify/d2s/s2d, uint8 layout
 convolutions differ only by fp32 accumulation order (<= 1 bf16 ulp on a small fraction); full
 decode/encode: stated tolerance rel-L2 <= 2e-2 (40+ bf16 layers)."""
 import parity
+import math
+
 import pytest
 import torch
 
@@ -64,6 +66,46 @@ def test_pixelnorm_act(dev, C, mod):
     out = V.pixelnorm_act(cl(x).to(dev), 1e-8, True, sc.to(dev) if mod else None, sh.to(dev) if mod else None)
     torch.cuda.synchronize()
     parity.auto(rel_l2(cf(out), ref), 3e-3)
+
+
+@pytest.mark.parametrize("C,res,mod,keep", [(128, False, False, False), (128, True, True, True), (256, True, False, True), (256, False, True, False)])
+def test_conv3d_fused_pixelnorm_act(dev, C, res, mod, keep):
+    """The PixelNorm (+ modulation) + SiLU carried by the conv epilogue (decoder.py:136-180) equals the conv followed by
+    ltxk_pixelnorm_act (same rounding points; only the association of the 128/256-term mean of squares differs, so a rare
+    element moves by one bf16 step), and equals the oracle's conv -> pixel_norm -> silu chain.  Ragged volume (rows past M
+    in the last tile), two batch rows with different modulation."""
+    from mlx_video_amd import video_vae as V
+    g = torch.Generator().manual_seed(C + res)
+    # more than 128 tiles, so that the un-fused reference launch is not split along K either (split-K sums in another order)
+    B, D, H, W = (2, 5, 64, 55) if C == 128 else (2, 3, 63, 56)
+    assert V.conv_act_fusable(C, B * D * H * W, force=True)
+    x = torch.randn(B, C, D, H, W, generator=g).to(BF)
+    w = (torch.randn(C, 3, 3, 3, C, generator=g) / math.sqrt(27 * C)).to(BF)
+    b = (torch.randn(C, generator=g) * 0.1).to(BF)
+    r = torch.randn(B, C, D, H, W, generator=g).to(BF) if res else None
+    sc = torch.randn(B, C, generator=g).to(BF) if mod else None
+    sh = torch.randn(B, C, generator=g).to(BF) if mod else None
+    dv = lambda t: None if t is None else t.to(dev)
+    act = dict(eps=1e-8, silu=True, scale=dv(sc), shift=dv(sh))
+    y_sep = V.conv3d(cl(x).to(dev), w.to(dev), b.to(dev), False, V.PAD_REFLECT, resid=dv(cl(r)) if res else None)
+    a_sep = V.pixelnorm_act(y_sep, 1e-8, True, dv(sc), dv(sh))
+    y_f, a_f = V.conv3d(cl(x).to(dev), w.to(dev), b.to(dev), False, V.PAD_REFLECT, resid=dv(cl(r)) if res else None, act=act, keep_out=keep)
+    torch.cuda.synchronize()
+    assert (y_f is None) == (not keep)
+    if keep:
+        assert torch.equal(y_f, y_sep)
+    mism = float((a_f != a_sep).float().mean())
+    assert mism < 2e-3, f"fused and separate PixelNorm outputs differ in {mism:.2%} of elements"
+    assert float((a_f.float() - a_sep.float()).abs().max()) <= 0.0625
+    p = O.BF16
+    ref = OV.causal_conv3d(x.float(), w.float(), b.float(), p, False, True)
+    if res:
+        ref = p.r(ref + r.float())
+    ref = OV.pixel_norm(ref, p, 1e-8)
+    if mod:
+        ref = OV._mod(ref, sc.float().reshape(B, C, 1, 1, 1), sh.float().reshape(B, C, 1, 1, 1), p)
+    ref = O.silu(ref, p)
+    parity.auto(rel_l2(cf(a_f), ref), 6e-3)
 
 
 def test_d2s_add_exact(dev):
