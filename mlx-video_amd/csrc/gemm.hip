@@ -429,6 +429,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 #endif
 }
 
+
 template <int TT, int EPI, int MODE>
 static int launch(const GemmParams& p, hipStream_t stream) {
   using G = GemmGeom<TT, 4>;
@@ -541,6 +542,13 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.RT = (a->M + bm - 1) / bm;
   p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
   hipStream_t st = (hipStream_t)stream;
+  // (A persistent form for the multi-round launches - one workgroup per CU walking tiles b, b+256, ..., the LDS-DMA
+  // stream running on across tiles, the bias slice arriving by LDS-DMA, y = bf16(acc+bias) kept packed and its activation
+  // + stores deferred band by band into the next tile's first K-steps - was built, bit-identical, and measured on FF1
+  // in the same process: 316.7 us against 315.4 us plain (GELU), 312.6 against 312.9 (bias).  Hiding the 0.6 us dispatch
+  // gap, the 2.0 us fill and the 5-7 us epilogue of three tile transitions bought nothing: these launches are
+  // power-limited (1.67-1.74 GHz held), and what paid instead was moving fewer bytes - the XCD patch order of map_tile.
+  // Removed again; git history has it.)
   switch (tt) {
     case 5: return dispatch_epi<5>(p, a->epilogue, trans, st);
     case 4: return dispatch_epi<4>(p, a->epilogue, trans, st);

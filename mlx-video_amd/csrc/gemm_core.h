@@ -52,22 +52,33 @@ struct GemmGeom {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS ring exceeds 160 KiB");
 };
 
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an
-// L2), so give each XCD a contiguous band of column tiles and walk it two column tiles at a
-// time over all row tiles: the 32 workgroups resident on an XCD then share 2 W panels and RT
-// A panels through that XCD's L2.  Placement affects speed only.
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Each XCD owns a band
+// of CT/8 column tiles and walks it in patches of 8 row tiles x 4 column tiles per 32-workgroup round: the round then
+// pulls 8 A panels + 4 W panels through that XCD's L2 (against 16 + 2 for "all row tiles x 2 columns": -25 % of the
+// L2->fabric reads, and the chip is power-limited in these launches - the first form of this patch order was worth
+// < 1 % on FF1 in round 1, the 16x16 case below 0.8 % of the whole block in round 2).  Column bands that are not a
+// multiple of 4 wide (q|k|v: 6) finish with a 2-column strip.  Placement affects speed only.
 __device__ __forceinline__ void map_tile(int bid, int RT, int CT, int& rt, int& ct) {
   if ((CT & 15) == 0) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int cpx = CT >> 3;                 // column tiles owned by this XCD
-    if ((cpx & 7) == 0 && (RT & 7) == 0) {
-      // 8 row tiles x 4 column tiles per 32-workgroup round: least L2->fabric traffic per round
-      // (8*a + 4*w panel bytes against 16*a + 2*w), see profiles/r01_pmc_traffic.md
-      const int per_cg = 4 * RT;             // workgroups per column group (all row tiles)
-      const int cg = idx / per_cg, j = idx - cg * per_cg;
-      const int rg = j >> 5, k = j & 31;     // row group of 8, position inside the 8x4 patch
-      rt = rg * 8 + (k >> 2);
-      ct = xcd * cpx + cg * 4 + (k & 3);
+    if (cpx == 2 && RT == 16) {
+      // 16 x 16 tiles = ONE round (FF2, out, q2, o2 at M=2560, N=4096): two XCDs share a 4-column group, one row half each
+      rt = (xcd & 1) * 8 + (idx >> 2);
+      ct = (xcd >> 1) * 4 + (idx & 3);
+    } else if ((RT & 7) == 0) {
+      const int full = (cpx >> 2) * 4 * RT;  // tiles of the band's whole 4-column groups
+      if (idx < full) {
+        const int per_cg = 4 * RT;           // workgroups per column group (all row tiles)
+        const int cg = idx / per_cg, j = idx - cg * per_cg;
+        const int rg = j >> 5, k = j & 31;   // row group of 8, position inside the 8x4 patch
+        rt = rg * 8 + (k >> 2);
+        ct = xcd * cpx + cg * 4 + (k & 3);
+      } else {
+        const int remc = cpx & 3, j = idx - full;      // the remaining 1-3 columns, all row tiles
+        rt = j / remc;
+        ct = xcd * cpx + (cpx >> 2) * 4 + (j - rt * remc);
+      }
     } else {
       const int pair = idx / (2 * RT), j = idx - pair * 2 * RT;
       rt = j >> 1;
