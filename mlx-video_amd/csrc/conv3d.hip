@@ -10,6 +10,7 @@
 //   M = B*D*H*W voxels (channels-last rows), N = Cout, K = 27*Cin walked tap-major in 64-wide
 //   steps; same 3-stage LDS ring / MFMA loop as the Linear GEMM (gemm_core.h).
 #include "gemm_core.h"
+#include <stdlib.h>
 #include <utility>
 
 namespace ltxk {
@@ -24,6 +25,7 @@ struct ConvParams {
   int ntaps, kd0;       // 27 taps from kd=0, or 9 taps at kd0=1 (per-frame 3x3 kernel)
   // fused PixelNorm (+ modulation) + SiLU of the output row (needs Cout == BN: the tile holds whole rows)
   bf16* act_out; const bf16* act_scale; const bf16* act_shift; float act_eps; int act_silu; int rows_per_batch;
+  int xcd_order;        // A/B switch (LTXK_CONV_XCD, default 1)
 };
 
 template <int TT, int WN, bool RES, bool SPLIT>
@@ -34,8 +36,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int tile = SPLIT ? blockIdx.x / p.S : blockIdx.x;
-  const int slice = SPLIT ? blockIdx.x - tile * p.S : 0;
+  // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): each XCD takes a CONTIGUOUS run of tiles, so
+  // the tiles in flight on one XCD are spatial neighbours and share their halo rows (4 image rows read per 2 written,
+  // x3 frames) and the weights through that XCD's L2 instead of each XCD fetching every halo itself.  Bijective for any
+  // tile count: XCD x owns q + (x < r) tiles, q = tiles / 8, r = tiles % 8.
+  int tile, slice = 0;
+  if constexpr (SPLIT) {
+    tile = blockIdx.x / p.S;
+    slice = blockIdx.x - tile * p.S;
+  } else {
+    const int nt_all = p.RT * p.CT, q = nt_all >> 3, r = nt_all & 7;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = p.xcd_order ? x * q + (x < r ? x : r) + j : (int)blockIdx.x;
+  }
   const int ct = tile % p.CT, rt = tile / p.CT;
   const int m0 = rt * G::BM, n0 = ct * G::BN;
   const int K = p.ntaps * p.Cin;
@@ -443,6 +456,7 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.ntaps = a->taps_d == 1 ? 9 : 27; p.kd0 = a->taps_d == 1 ? 1 : 0;
   p.act_out = (bf16*)a->act_out; p.act_scale = (const bf16*)a->act_scale; p.act_shift = (const bf16*)a->act_shift;
   p.act_eps = a->act_eps; p.act_silu = a->act_silu; p.rows_per_batch = a->D * a->H * a->W;
+  { const char* e = getenv("LTXK_CONV_XCD"); p.xcd_order = e ? atoi(e) : 1; }
   if (a->act_out) {
     LTXK_CHECK_ARG(a->Cout == 128 || a->Cout == 256, "ltxk_conv3d_k3_bf16: the fused norm/activation output needs Cout == 128 or 256 (got %d)", a->Cout);
     LTXK_CHECK_ARG((a->act_scale == nullptr) == (a->act_shift == nullptr), "ltxk_conv3d_k3_bf16: act_scale and act_shift must both be set or both NULL");
