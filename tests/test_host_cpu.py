@@ -272,3 +272,41 @@ def test_bench_flop_accounting_matches_survey_table():
     assert abs((full - executed) - (2 * 2 * 1280 - 2) * (256 * D + D * D + 6 * D * D)) < 1e6
     assert 69.5e12 < full < 69.9e12                       # the 69.7 TFLOP/step the bench line quotes
     assert len(bench.source_sha()) == 16
+
+
+def test_gemm_tile_order_is_a_bijection(tmp_path):
+    """map_tile (csrc/gemm_core.h) permutes workgroup ids onto tiles for L2 locality; whatever the shape it must hit every
+    tile exactly once.  The function is plain integer C++: its text is compiled for the host with g++ and swept over the
+    tile grids the model produces and a set of awkward ones."""
+    import re
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    src = open(os.path.join(ROOT, "mlx-video_amd", "csrc", "gemm_core.h")).read()
+    m = re.search(r"__device__ __forceinline__ void map_tile\(.*?\n}\n", src, re.S)
+    assert m, "map_tile not found"
+    body = m.group(0).replace("__device__ __forceinline__", "static")
+    prog = body + r"""
+#include <cstdio>
+#include <vector>
+int main() {
+  const int cfgs[][2] = {{16,16},{16,64},{16,48},{16,32},{8,16},{24,48},{16,80},{13,16},{16,112},{32,16},{5,3},{16,24},{1,1},{7,128},
+                         {33,16},{41,32},{16,96},{8,48},{2,16},{40,2},{11,64}};
+  for (auto& c : cfgs) {
+    const int RT = c[0], CT = c[1];
+    std::vector<int> seen(RT * CT, 0);
+    for (int b = 0; b < RT * CT; ++b) {
+      int rt = -1, ct = -1;
+      map_tile(b, RT, CT, rt, ct);
+      if (rt < 0 || rt >= RT || ct < 0 || ct >= CT || seen[rt * CT + ct]++) { printf("FAIL RT=%d CT=%d bid=%d -> (%d,%d)\n", RT, CT, b, rt, ct); return 1; }
+    }
+  }
+  printf("OK\n");
+  return 0;
+}
+"""
+    (tmp_path / "m.cpp").write_text(prog)
+    subprocess.run(["g++", "-O1", "-o", str(tmp_path / "m"), str(tmp_path / "m.cpp")], check=True)
+    out = subprocess.run([str(tmp_path / "m")], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "OK", out.stdout
