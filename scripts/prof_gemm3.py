@@ -13,6 +13,8 @@ for spec in sys.argv[2:]:
     a = torch.randn((M, K), generator=g, device=dev).to(torch.bfloat16)
     w = (torch.randn((N, K), generator=g, device=dev) * 0.02).to(torch.bfloat16)
     b = (torch.randn(N, generator=g, device=dev) * 0.01).to(torch.bfloat16)
+    if os.environ.get("GEMM_ZERO_DATA") == "1":          # DVFS probe: all-zero operands draw less power per MFMA
+        a.zero_(); w.zero_()
     kw = dict(epilogue=epi)
     if split:
         T = M // 2
