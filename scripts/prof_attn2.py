@@ -13,6 +13,8 @@ for spec in sys.argv[2:]:
     k = torch.randn((B * Tk, D), generator=g, device=dev).to(torch.bfloat16)
     vt = torch.randn((B, D, (Tk + 63) // 64 * 64), generator=g, device=dev).to(torch.bfloat16)
     out = torch.empty((B * Tq, D), dtype=torch.bfloat16, device=dev)
+    if os.environ.get("ATTN_ZERO_DATA") == "1":          # DVFS probe (all-zero operands; the softmax still runs every instruction)
+        q.zero_(); k.zero_(); vt.zero_()
     for _ in range(3):
         ops.flash_attn(q, k, vt, out, B, H, Tq, Tk, 1 / math.sqrt(128))
     torch.cuda.synchronize()
