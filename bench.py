@@ -281,7 +281,11 @@ def main() -> None:
         rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
                                   "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
-                                  "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"]}
+                                  "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"],
+                                  # context, not a second roofline: bf16 GEMMs on random data are power-limited on this chip
+                                  "power_limited_reference": {"tuned_bf16_gemm_random_data_tflops": 1247.0,
+                                                              "source": "MI355X_MICROARCH.md (DVFS give-back); these binaries on all-zero operands: "
+                                                                        "1433-1542 TF/s (profiles/r02_gemm_zero_vs_random.log)"}}
     if "flash_attn" in fams:
         fa = fams["flash_attn"]
         ach = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
