@@ -215,6 +215,9 @@ struct MmaPipe {
     auto rd = [&](int idx) {
       const int ks = idx / (4 + TT), r = idx % (4 + TT);
       const int ko = ks ? koff1 : koff0;
+#ifdef LTXK_PROBE_FEWER_LDS_READS      // energy probe only (WRONG results): the ks=1 fragments are copies of the ks=0 ones
+      if (ks == 1) { if (r < 4) wf[1][r] = wf[0][r]; else af[1][r - 4] = af[0][r - 4]; return; }
+#endif
       if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
       else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
     };
