@@ -488,6 +488,187 @@ static int pick_tt(int M, int N) {
 
 }  // namespace ltxk
 
+// ---- 320 x 256 tile for the widest Linear (FF1: M=2560, N=16384) ------------------------------------------------------
+// These launches run at the chip's power limit, and what an MFMA costs in energy besides itself is mostly the L2 -> LDS
+// stream that feeds it (scripts/mfma_power_probe.hip: the 160x256 kernel's instruction mix sustains 1.21-1.24 PF in a
+// synthetic loop, the kernel itself 1.1-1.2; the mix of a 320x256 tile sustains 1.41).  Doubling the tile takes 31 % off
+// the LDS-DMA bytes per MFMA, 22 % off the L2 -> fabric bytes (8x4 patches of 320-row tiles) and, with 80x128 per wave,
+// 28 % off the fragment reads.  The price is registers: 160 accumulator registers per lane at two waves per SIMD leave
+// room for ONE set of operand fragments, so a wave reads, waits and multiplies (the SIMD's other wave covers the wait),
+// refilling each fragment register as soon as its last MFMA of the K-sub-step has issued; and LDS holds two stages, not
+// three, so a stage's LDS-DMA pieces are all issued in the first MFMA groups of the step before it.
+// The accumulators live in VGPRs (gfx950's register file is unified; a kernel that names AGPRs gets its 256-register
+// budget split 128 / 128 by hipcc, which 160 accumulators do not fit): the MFMAs are inline asm, accumulating in place.  Only launches that fill whole rounds use it (dispatch below).
+namespace ltxk {
+
+constexpr int BIG_BM = 320, BIG_BN = 256;
+constexpr int BIG_STAGE_W = BIG_BN * 128, BIG_STAGE = (BIG_BN + BIG_BM) * 128, BIG_LDS = 2 * BIG_STAGE;
+static_assert(BIG_LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+
+#define LTXK_MFMA_V(acc, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a))
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int rt, ct;
+  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
+  const int m0 = rt * BIG_BM, n0 = ct * BIG_BN;
+  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves of 80 x 128
+
+  // loader: 32 W pieces + 40 A pieces of 1 KiB (8 rows x 128 B) per stage; wave w owns W pieces 4w..4w+3 and A pieces
+  // 5w..5w+4.  Source = wave-uniform base (SGPR) + per-lane offset; the 16-byte chunk is pre-swizzled by the row.
+  const int lrow = lane >> 3;
+  const int chunk = (lane & 7) ^ lrow;
+  const unsigned w_lane = (unsigned)((lrow * p.K + chunk * 8) * 2);
+  const uint64_t w_base = (uint64_t)(p.W + (size_t)(n0 + wave * 32) * p.K);
+  unsigned a_lane[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int r = m0 + (wave * 5 + i) * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    a_lane[i] = (unsigned)(((size_t)(r - m0) * p.lda + chunk * 8) * 2);
+  }
+  const uint64_t a_base = (uint64_t)(p.A + (size_t)m0 * p.lda);
+  auto issue_piece = [&](int i, int kt, int slot) __attribute__((always_inline)) {
+    char* base = smem + slot * BIG_STAGE;
+    const unsigned ko = (unsigned)(kt * GEMM_BK * 2);
+    if (i < 4) glds16_s(w_base + (uint64_t)i * 8 * p.K * 2 + ko, w_lane, base + (wave * 4 + i) * 1024);
+    else if (i < 9) glds16_s(a_base + ko, a_lane[i - 4 < 5 ? i - 4 : 0], base + BIG_STAGE_W + (wave * 5 + (i - 4)) * 1024);
+  };
+
+  f32x4 acc[5][8];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GEMM_BK;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) issue_piece(i, 0, 0);
+
+  const int frow = (lane & 15) * 128;
+  const int koff0 = ((lane >> 4) ^ (lane & 7)) << 4;
+  const int koff1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+  bf16x8 wf[8], af[5];
+  for (int kt = 0; kt < nk; ++kt) {
+    // stage kt has landed in every wave's view, and every wave has finished reading the other slot (stage kt-1)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int slot = kt & 1;
+    const char* wb = smem + slot * BIG_STAGE + (wn * 128) * 128 + frow;
+    const char* ab = smem + slot * BIG_STAGE + BIG_STAGE_W + (wm * 80) * 128 + frow;
+    const int kt1 = kt + 1 < nk ? kt + 1 : nk - 1;                // tail: harmless re-load of the last stage
+    // K-sub-step 0 fragments, in the order the first MFMA row consumes them
+    // (fenced one by one: the first MFMA then waits for two reads, not for thirteen)
+    af[0] = *(const bf16x8*)(ab + koff0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wf[j] = *(const bf16x8*)(wb + j * 2048 + koff0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 1; i < 5; ++i) af[i] = *(const bf16x8*)(ab + i * 2048 + koff0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          LTXK_MFMA_V(acc[i][j], wf[j], af[i]);
+          // the last row of sub-step 0 frees the W fragments one by one: refill each for sub-step 1 at once
+          if (ks == 0 && i == 4) wf[j] = *(const bf16x8*)(wb + j * 2048 + koff1);
+        }
+        if (ks == 0) {
+          af[i] = *(const bf16x8*)(ab + i * 2048 + koff1);        // row i done: its A fragment register is free
+          // next stage's LDS-DMA: all nine pieces in the first three MFMA rows, so they have most of a K-step to land
+          if (i < 3) {
+            issue_piece(i * 3 + 0, kt1, slot ^ 1);
+            issue_piece(i * 3 + 1, kt1, slot ^ 1);
+            issue_piece(i * 3 + 2, kt1, slot ^ 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // hipcc does not see the asm MFMAs as matrix instructions and pads no hazard: let the last ones retire before the
+  // accumulators are read (the operands tie the wait to the registers written last)
+  asm volatile("s_nop 15\n\ts_nop 15"
+               : "+v"(acc[3][4]), "+v"(acc[3][5]), "+v"(acc[3][6]), "+v"(acc[3][7]), "+v"(acc[4][0]), "+v"(acc[4][1]),
+                 "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[4][4]), "+v"(acc[4][5]), "+v"(acc[4][6]), "+v"(acc[4][7]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: acc[i][j][q]: row = lane & 15, column = 4 * (lane >> 4) + q; direct 8-byte stores ----
+  const int nq = (lane >> 4) * 4;
+  bf16x4 bpre[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + wn * 128 + j * 16 + nq;
+    bpre[j] = p.bias ? *(const bf16x4*)(p.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int m = m0 + wm * 80 + i * 16 + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (m >= p.M) continue;
+      const int n = n0 + wn * 128 + j * 16 + nq;
+      float y[4];
+      if (p.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q] + (float)bpre[j][q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q]);
+      }
+      if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = gelu_tanh_f(y[q]);
+      } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = silu_f(y[q]);
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (bf16)y[q];
+      *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+    }
+  }
+}
+
+template <int EPI>
+static int launch_big(const GemmParams& p, hipStream_t stream) {
+  auto kern = gemm_bf16_big_kernel<EPI>;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, BIG_LDS);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(512), BIG_LDS, stream, p);
+  LTXK_CHECK_LAUNCH("ltxk_gemm_bf16");
+  return LTXK_OK;
+}
+
+// The big tile pays when it still fills whole 256-CU rounds: rounds x 2 (tile area) x 0.9 (measured gain) against the
+// 160-row rounds.  M=2560: N=16384 -> 2 rounds against 4 (taken); N=12288 -> 2 against 3, N=4096 -> 1 against 1 (not).
+static bool big_tile_pays(int M, int N) {
+  const long CT = N / BIG_BN;
+  const long rounds_b = (((M + BIG_BM - 1) / BIG_BM) * CT + 255) / 256;
+  const long rounds_s = (((M + 159) / 160) * CT + 255) / 256;
+  return rounds_b * 18 < rounds_s * 10;
+}
+
+}  // namespace ltxk
+
 extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   using namespace ltxk;
   LTXK_CHECK_ARG(a != nullptr, "ltxk_gemm_bf16: null args");
@@ -542,6 +723,19 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.RT = (a->M + bm - 1) / bm;
   p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
   hipStream_t st = (hipStream_t)stream;
+  // 0: off, 2: whenever legal (tests); read per call so that one process can compare both forms
+  const int big_env = [] { const char* e = getenv("LTXK_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  const bool big_legal = !trans && !split && !a->sumsq && a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
+                         (a->epilogue == LTXK_EPI_BIAS || a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU);
+  if (big_legal && tt_env == 0 && (big_env == 2 || (big_env == 1 && big_tile_pays(a->M, a->N)))) {
+    p.RT = (a->M + BIG_BM - 1) / BIG_BM;
+    p.CT = a->N / BIG_BN;
+    switch (a->epilogue) {
+      case LTXK_EPI_BIAS: return launch_big<LTXK_EPI_BIAS>(p, st);
+      case LTXK_EPI_BIAS_GELU: return launch_big<LTXK_EPI_BIAS_GELU>(p, st);
+      default: return launch_big<LTXK_EPI_BIAS_SILU>(p, st);
+    }
+  }
   // (A persistent form for the multi-round launches - one workgroup per CU walking tiles b, b+256, ..., the LDS-DMA
   // stream running on across tiles, the bias slice arriving by LDS-DMA, y = bf16(acc+bias) kept packed and its activation
   // + stores deferred band by band into the next tile's first K-steps - was built, bit-identical, and measured on FF1

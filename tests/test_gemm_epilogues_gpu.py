@@ -60,3 +60,49 @@ def test_gemm_epilogues_deterministic(dev, M, N, K):
                 assert torch.equal(outs[0], o), f"epilogue {epi} bias={use_bias}: results differ between launches"
             worst = max(worst, float((outs[0].float() - ref).norm() / ref.norm()))
     parity.auto(worst, 6e-3)
+
+
+BIG_SHAPES = [(320, 256, 64), (2560, 1024, 256), (700, 512, 192), (2560, 4096, 1024), (1296, 768, 448)]
+
+
+@pytest.mark.parametrize("M,N,K", BIG_SHAPES)
+def test_gemm_320x256_tile_equals_160x256_tile(dev, M, N, K, monkeypatch):
+    """The 320x256-tile kernel (gemm.hip, taken for FF1-sized launches) walks K in the same order with the same MFMA as
+    the 160x256 one: forced on (LTXK_GEMM_BIG=2) it must give the same bits, for every epilogue it supports, with and
+    without bias, with a ragged last row tile (M=700, 1296) and when its output is a strided view."""
+    from mlx_video_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M * 3 + N + K)
+    a = torch.randn((M, K), generator=g, device=dev).to(BF)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(BF)
+    b = (torch.randn(N, generator=g, device=dev) * 0.1).to(BF)
+    for epi in (0, 1, 2):
+        for bias in (b, None):
+            outs = {}
+            for mode in ("0", "2"):
+                monkeypatch.setenv("LTXK_GEMM_BIG", mode)
+                buf = torch.full((M + 1, N + 64), 7.0, device=dev, dtype=BF)
+                ops.gemm(a, w, bias, out=buf[:M, :N], epilogue=epi)
+                torch.cuda.synchronize()
+                assert torch.all(buf[M:] == 7.0) and torch.all(buf[:, N:] == 7.0), "wrote outside the output view"
+                outs[mode] = buf[:M, :N].clone()
+            assert torch.equal(outs["0"], outs["2"]), f"epilogue {epi} bias={bias is not None}"
+    monkeypatch.setenv("LTXK_GEMM_BIG", "2")
+    acc = a.float() @ w.float().t()
+    ref = torch.nn.functional.gelu((acc + b.float()).to(BF).float(), approximate="tanh")
+    out = ops.gemm(a, w, b, epilogue=1)
+    parity.check(f"gemm.big_tile_gelu_{M}x{N}x{K}_vs_torch_fp32", float((out.float() - ref).norm() / ref.norm()), 6e-3)
+
+
+def test_gemm_ff1_takes_the_320x256_tile(dev, monkeypatch):
+    """Default dispatch at the FF1 shape (M=2560, N=16384, K=4096): same bits as with the big tile switched off."""
+    from mlx_video_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = torch.randn((2560, 4096), generator=g, device=dev).to(BF)
+    w = (torch.randn((16384, 4096), generator=g, device=dev) * 0.02).to(BF)
+    b = (torch.randn(16384, generator=g, device=dev) * 0.1).to(BF)
+    monkeypatch.delenv("LTXK_GEMM_BIG", raising=False)
+    y1 = ops.gemm(a, w, b, epilogue=1)
+    monkeypatch.setenv("LTXK_GEMM_BIG", "0")
+    y0 = ops.gemm(a, w, b, epilogue=1)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
