@@ -505,16 +505,17 @@ constexpr int BIG_BM = 320, BIG_BN = 256;
 constexpr int BIG_STAGE_W = BIG_BN * 128, BIG_STAGE = (BIG_BN + BIG_BM) * 128, BIG_LDS = 2 * BIG_STAGE;
 static_assert(BIG_LDS <= 160 * 1024, "two stages must fit the CU's LDS");
 
+#ifndef LTXK_BIG_PPR
+#define LTXK_BIG_PPR 3   // LDS-DMA pieces issued per MFMA row of sub-step 0
+#endif
+#ifndef LTXK_BIG_HELD
+#define LTXK_BIG_HELD 1  // W columns of sub-step 1 held back past the next barrier (5 MFMAs each)
+#endif
 #define LTXK_MFMA_V(acc, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a))
 
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int rt, ct;
-  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
-  const int m0 = rt * BIG_BM, n0 = ct * BIG_BN;
+// TRANS: the tile is written transposed per batch (V^T) - operand roles swapped so that a lane holds 4 consecutive tokens
+template <int EPI, bool TRANS>
+__device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, int m0, int n0, int wave, int lane) {
   const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves of 80 x 128
 
   // loader: 32 W pieces + 40 A pieces of 1 KiB (8 rows x 128 B) per stage; wave w owns W pieces 4w..4w+3 and A pieces
@@ -552,6 +553,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
   const int koff0 = ((lane >> 4) ^ (lane & 7)) << 4;
   const int koff1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
   bf16x8 wf[8], af[5];
+  auto mma = [](f32x4& c, const bf16x8& w, const bf16x8& a) __attribute__((always_inline)) {
+    if constexpr (TRANS) LTXK_MFMA_V(c, a, w);
+    else LTXK_MFMA_V(c, w, a);
+  };
+  // The last W column(s) of every K-step's second half (5 MFMAs per wave each) are held back until AFTER the next step's barrier:
+  // its operands are in registers, so it runs while the new stage's first fragment reads are in flight - the LDS cold start
+  // after each barrier (all 8 waves reading at once) then does not idle the matrix pipe.  Step 0 multiplies zeros.
+  constexpr int HB = LTXK_BIG_HELD;                                // held-back W columns: 8-HB .. 7
+#pragma unroll
+  for (int j = 8 - HB; j < 8; ++j)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) wf[j][q] = (bf16)0.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) af[i][q] = (bf16)0.f;
   for (int kt = 0; kt < nk; ++kt) {
     // stage kt has landed in every wave's view, and every wave has finished reading the other slot (stage kt-1)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -559,89 +576,168 @@ __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
     const char* wb = smem + slot * BIG_STAGE + (wn * 128) * 128 + frow;
     const char* ab = smem + slot * BIG_STAGE + BIG_STAGE_W + (wm * 80) * 128 + frow;
     const int kt1 = kt + 1 < nk ? kt + 1 : nk - 1;                // tail: harmless re-load of the last stage
-    // K-sub-step 0 fragments, in the order the first MFMA row consumes them
-    // (fenced one by one: the first MFMA then waits for two reads, not for thirteen)
-    af[0] = *(const bf16x8*)(ab + koff0);
-    __builtin_amdgcn_sched_barrier(0);
+    // K-sub-step 0 fragments.  The W fragments whose registers are free first, then the held-back columns, each of their
+    // last MFMAs freeing one A fragment register for the new stage, then the remaining W fragments.
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 8 - HB; ++j) {
       wf[j] = *(const bf16x8*)(wb + j * 2048 + koff0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 1; i < 5; ++i) af[i] = *(const bf16x8*)(ab + i * 2048 + koff0);
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+      for (int j = 8 - HB; j < 8; ++j) mma(acc[i][j], wf[j], af[i]);
+      af[i] = *(const bf16x8*)(ab + i * 2048 + koff0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 8 - HB; j < 8; ++j) wf[j] = *(const bf16x8*)(wb + j * 2048 + koff0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          LTXK_MFMA_V(acc[i][j], wf[j], af[i]);
+        for (int j = 0; j < (ks == 0 ? 8 : 8 - HB); ++j) {
+          mma(acc[i][j], wf[j], af[i]);
           // the last row of sub-step 0 frees the W fragments one by one: refill each for sub-step 1 at once
           if (ks == 0 && i == 4) wf[j] = *(const bf16x8*)(wb + j * 2048 + koff1);
         }
         if (ks == 0) {
           af[i] = *(const bf16x8*)(ab + i * 2048 + koff1);        // row i done: its A fragment register is free
           // next stage's LDS-DMA: all nine pieces in the first three MFMA rows, so they have most of a K-step to land
-          if (i < 3) {
-            issue_piece(i * 3 + 0, kt1, slot ^ 1);
-            issue_piece(i * 3 + 1, kt1, slot ^ 1);
-            issue_piece(i * 3 + 2, kt1, slot ^ 1);
-          }
+#pragma unroll
+          for (int q = 0; q < LTXK_BIG_PPR; ++q) issue_piece(i * LTXK_BIG_PPR + q, kt1, slot ^ 1);   // (no-op past piece 8)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 8 - HB; j < 8; ++j) mma(acc[i][j], wf[j], af[i]);
   // hipcc does not see the asm MFMAs as matrix instructions and pads no hazard: let the last ones retire before the
   // accumulators are read (the operands tie the wait to the registers written last)
   asm volatile("s_nop 15\n\ts_nop 15"
                : "+v"(acc[3][4]), "+v"(acc[3][5]), "+v"(acc[3][6]), "+v"(acc[3][7]), "+v"(acc[4][0]), "+v"(acc[4][1]),
-                 "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[4][4]), "+v"(acc[4][5]), "+v"(acc[4][6]), "+v"(acc[4][7]));
+                 "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[4][4]), "+v"(acc[4][5]), "+v"(acc[4][6]), "+v"(acc[4][7]),
+                 "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[2][7]), "+v"(acc[0][6]), "+v"(acc[1][6]), "+v"(acc[2][6]), "+v"(acc[0][5]), "+v"(acc[1][5]), "+v"(acc[2][5]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue: acc[i][j][q]: row = lane & 15, column = 4 * (lane >> 4) + q; direct 8-byte stores ----
-  const int nq = (lane >> 4) * 4;
-  bf16x4 bpre[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = n0 + wn * 128 + j * 16 + nq;
-    bpre[j] = p.bias ? *(const bf16x4*)(p.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-  }
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int m = m0 + wm * 80 + i * 16 + (lane & 15);
+  if constexpr (!TRANS) {
+    // ---- epilogue: acc[i][j][q]: row = lane & 15, column = 4 * (lane >> 4) + q; direct 8-byte stores ----
+    const int nq = (lane >> 4) * 4;
+    const bool want_ss = p.sumsq != nullptr;
+    bf16x4 bpre[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (m >= p.M) continue;
       const int n = n0 + wn * 128 + j * 16 + nq;
-      float y[4];
-      if (p.bias) {
+      bpre[j] = p.bias ? *(const bf16x4*)(p.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q] + (float)bpre[j][q]);
-      } else {
+    for (int i = 0; i < 5; ++i) {
+      const int m = m0 + wm * 80 + i * 16 + (lane & 15);
+      float ss[2] = {0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q]);
+      for (int j = 0; j < 8; ++j) {
+        if (m >= p.M) continue;
+        const int n = n0 + wn * 128 + j * 16 + nq;
+        float y[4];
+        if (p.bias) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q] + (float)bpre[j][q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = rbf(acc[i][j][q]);
+        }
+        if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = gelu_tanh_f(y[q]);
+        } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = silu_f(y[q]);
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (bf16)y[q];
+        if (want_ss) {                  // the 160x256 kernel's order: 16 values per lane and 64-column block, then the 4 lanes
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float f = (float)o[q];
+            ss[j >> 2] += f * f;
+          }
+        }
+        *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
       }
-      if constexpr (EPI == LTXK_EPI_BIAS_GELU) {
+      if (want_ss) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = gelu_tanh_f(y[q]);
-      } else if constexpr (EPI == LTXK_EPI_BIAS_SILU) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) y[q] = silu_f(y[q]);
+        for (int b = 0; b < 2; ++b) {
+          float v = ss[b];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (lane < 16 && m < p.M) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 128) >> 6) + b] = v;
+        }
       }
-      bf16x4 o;
+    }
+  } else {
+    // acc[i][j][q]: n = lane & 15, token = 4 * (lane >> 4) + q; out[(b * tN + n - n_split) * ld + t]  (as the 160x256 kernel)
+    const int tq = (lane >> 4) * 4;
+    bf16* const tout = p.n_split ? p.out2 : p.out;
+    const int tld = p.n_split ? p.ldo2 : p.ldo;
+    const int tN = p.N - p.n_split;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = (bf16)y[q];
-      *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+    for (int j = 0; j < 8; ++j) {
+      const int n = n0 + wn * 128 + j * 16 + (lane & 15);
+      const float b = p.bias ? (float)p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int m = m0 + wm * 80 + i * 16 + tq;
+        if (m >= p.M) continue;
+        bf16x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (bf16)(acc[i][j][q] + b);
+        const int bidx = m / p.T, t = m - bidx * p.T;
+        bf16* dst = tout + ((size_t)bidx * tN + (n - p.n_split)) * tld + t;
+        if ((p.T & 3) == 0 && m + 3 < p.M) {
+          *(bf16x4*)dst = o;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int mq = m + q;
+            if (mq < p.M) {
+              const int bq = mq / p.T, tqq = mq - bq * p.T;
+              tout[((size_t)bq * tN + (n - p.n_split)) * tld + tqq] = o[q];
+            }
+          }
+        }
+      }
     }
   }
 }
 
-template <int EPI>
+// MODE as in gemm_bf16_kernel: 0 row-major with EPI, 1 transposed, 2 split at n_split
+template <int EPI, int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int rt, ct;
+  map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
+  const int m0 = rt * BIG_BM, n0 = ct * BIG_BN;
+  if constexpr (MODE == 0) {
+    gemm_big_tile<EPI, false>(p, smem, m0, n0, wave, lane);
+  } else if constexpr (MODE == 1) {
+    gemm_big_tile<LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+  } else {
+    if (n0 < p.n_split) gemm_big_tile<EPI, false>(p, smem, m0, n0, wave, lane);
+    else gemm_big_tile<LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+  }
+}
+
+template <int EPI, int MODE>
 static int launch_big(const GemmParams& p, hipStream_t stream) {
-  auto kern = gemm_bf16_big_kernel<EPI>;
+  auto kern = gemm_bf16_big_kernel<EPI, MODE>;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -725,15 +821,17 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // 0: off, 2: whenever legal (tests); read per call so that one process can compare both forms
   const int big_env = [] { const char* e = getenv("LTXK_GEMM_BIG"); return e ? atoi(e) : 1; }();
-  const bool big_legal = !trans && !split && !a->sumsq && a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
-                         (a->epilogue == LTXK_EPI_BIAS || a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU);
+  const bool big_legal = a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
+                         (a->epilogue == LTXK_EPI_BIAS || ((a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU) && !a->sumsq));
   if (big_legal && tt_env == 0 && (big_env == 2 || (big_env == 1 && big_tile_pays(a->M, a->N)))) {
     p.RT = (a->M + BIG_BM - 1) / BIG_BM;
     p.CT = a->N / BIG_BN;
+    if (split) return launch_big<LTXK_EPI_BIAS, 2>(p, st);
+    if (trans) return launch_big<LTXK_EPI_BIAS, 1>(p, st);
     switch (a->epilogue) {
-      case LTXK_EPI_BIAS: return launch_big<LTXK_EPI_BIAS>(p, st);
-      case LTXK_EPI_BIAS_GELU: return launch_big<LTXK_EPI_BIAS_GELU>(p, st);
-      default: return launch_big<LTXK_EPI_BIAS_SILU>(p, st);
+      case LTXK_EPI_BIAS: return launch_big<LTXK_EPI_BIAS, 0>(p, st);
+      case LTXK_EPI_BIAS_GELU: return launch_big<LTXK_EPI_BIAS_GELU, 0>(p, st);
+      default: return launch_big<LTXK_EPI_BIAS_SILU, 0>(p, st);
     }
   }
   // (A persistent form for the multi-round launches - one workgroup per CU walking tiles b, b+256, ..., the LDS-DMA

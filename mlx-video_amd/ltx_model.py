@@ -134,8 +134,11 @@ class LTXModel:
         self.timestep_scale_multiplier = config.timestep_scale_multiplier
         # A/B switches of the launch structure (scripts/ab_step.py; all three forms give the same roundings):
         #   1: q|k|v and text k|v as ONE GEMM launch with a split output;  2: row sums of squares carried by the GEMM
-        #   epilogues into the norm kernels;  4: q_norm + RoPE of q applied inside the attention kernel (needs 2)
-        self.fuse = int(os.environ.get("LTXK_FUSE", "7"))
+        #   epilogues into the norm kernels;  4: q_norm + RoPE of q applied inside the attention kernel (needs 2);
+        #   8: self-attention q|k and v as TWO launches after all - q|k (N=8192) then fills exactly one round of the
+        #   320x256-tile kernel, 152 + 74 us against 239 us for the one q|k|v launch on 160x256 tiles at M=2560
+        #   (profiles/r02_gemm_big_tile_ab.log); the text k|v pair stays one launch (it takes the big tile as it is)
+        self.fuse = int(os.environ.get("LTXK_FUSE", "15"))
         self._pack(weights)
 
     # ------------------------------------------------------------------ weights
@@ -370,7 +373,7 @@ class LTXModel:
             # V^T transposed.  k is normalised + rotated in place; q stays RAW in HBM - the attention kernel normalises
             # and rotates its Q fragments in registers (attention.py:129-136).
             ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
-            if fq:
+            if fq and not (self.fuse & 8):
                 ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=s_qk)
             else:
                 ops.gemm(nx, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=qk, sumsq=s_qk)

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 iters = int(sys.argv[1])
 for spec in sys.argv[2:]:
     f = spec.split(":")
-    M, N, K = map(int, f[:3]); epi = int(f[3]) if len(f) > 3 else 0; split = len(f) > 4 and f[4] == "1"
+    M, N, K = map(int, f[:3]); epi = int(f[3]) if len(f) > 3 else 0; split = len(f) > 4 and f[4] in ("1", "2"); half = len(f) > 4 and f[4] == "2"    # 2: k | V^T halves (text K/V)
     g = torch.Generator(device=dev).manual_seed(0)
     a = torch.randn((M, K), generator=g, device=dev).to(torch.bfloat16)
     w = (torch.randn((N, K), generator=g, device=dev) * 0.02).to(torch.bfloat16)
@@ -18,8 +18,9 @@ for spec in sys.argv[2:]:
     kw = dict(epilogue=epi)
     if split:
         T = M // 2
-        kw.update(out=torch.empty((M, N * 2 // 3), device=dev, dtype=torch.bfloat16), out2=torch.empty((2, N // 3, T), device=dev, dtype=torch.bfloat16),
-                  n_split=N * 2 // 3, out_tokens_per_batch=T, sumsq=torch.empty((M, N * 2 // 3 // 64), device=dev, dtype=torch.float32))
+        ns = N // 2 if half else N * 2 // 3
+        kw.update(out=torch.empty((M, ns), device=dev, dtype=torch.bfloat16), out2=torch.empty((2, N - ns, T), device=dev, dtype=torch.bfloat16),
+                  n_split=ns, out_tokens_per_batch=T, sumsq=torch.empty((M, ns // 64), device=dev, dtype=torch.float32))
     else:
         kw.update(out=torch.empty((M, N), device=dev, dtype=torch.bfloat16))
         if epi in (3, 4):

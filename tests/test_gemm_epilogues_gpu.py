@@ -106,3 +106,38 @@ def test_gemm_ff1_takes_the_320x256_tile(dev, monkeypatch):
     y0 = ops.gemm(a, w, b, epilogue=1)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("M,N,K", [(2560, 1024, 256), (700, 512, 192), (2048, 768, 320)])
+def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monkeypatch):
+    """Row statistics, the transposed (V^T) output - vector stores at T % 4 == 0, element stores at T = 350 - and the
+    split k | V^T output of the 320x256-tile kernel against the 160x256 one: same bits."""
+    from mlx_video_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N * 7 + K)
+    a = torch.randn((M, K), generator=g, device=dev).to(BF)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(BF)
+    b = (torch.randn(N, generator=g, device=dev) * 0.1).to(BF)
+    T = M // 2
+    ld = (T + 63) // 64 * 64
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("LTXK_GEMM_BIG", mode)
+        ss = torch.full((M, N // 64 + 1), -1.0, device=dev, dtype=torch.float32)
+        y = ops.gemm(a, w, b, sumsq=ss)
+        vt = torch.full((2, N, ld), 3.0, device=dev, dtype=BF)
+        ops.gemm(a, w, b, out=vt, out_tokens_per_batch=T)
+        ns = 256
+        k2 = torch.empty((M, ns), device=dev, dtype=BF)
+        v2 = torch.full((2, N - ns, ld), 3.0, device=dev, dtype=BF)
+        ss2 = torch.full((M, ns // 64), -1.0, device=dev, dtype=torch.float32)
+        ops.gemm(a, w, b, out=k2, out2=v2, n_split=ns, out_tokens_per_batch=T, sumsq=ss2)
+        torch.cuda.synchronize()
+        res[mode] = (y, ss, vt, k2, v2, ss2)
+    for name, x0, x2 in zip(("y", "sumsq", "vt", "split.k", "split.vt", "split.sumsq"), res["0"], res["2"]):
+        assert torch.equal(x0, x2), name
+    y, ss, vt, k2, v2, ss2 = res["2"]
+    assert torch.all(ss[:, -1] == -1.0) and torch.all(vt[:, :, T:] == 3.0)
+    assert torch.equal(vt[:, :, :T], y.reshape(2, T, N).transpose(1, 2))
+    assert torch.equal(k2, y[:, :256]) and torch.equal(v2[:, :, :T], vt[:, 256:, :T])
+    ref = (y.float() ** 2).reshape(M, N // 64, 64).sum(-1)
+    assert float((ss[:, :-1] - ref).abs().max() / ref.abs().max()) < 1e-5
