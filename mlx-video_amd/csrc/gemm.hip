@@ -754,6 +754,11 @@ static int launch_big(const GemmParams& p, hipStream_t stream) {
   return LTXK_OK;
 }
 
+// (FF2 - N=4096, K=16384: 128 big tiles - was also tried on this tile as split-K pairs, two workgroups per tile with one K
+// half each, the first to finish parking its fp32 partial tile in a workspace, the second adding it and running the
+// gate + residual epilogue: 416 us against 302 us with agent-scope release / acquire fences around the hand-over (each is
+// a whole-L2 write-back / invalidate on this chip), and still 320 us with the fences taken out for the measurement; at
+// K=4096 116 against 90 us.  The meeting costs more than the bigger tile saves.  Removed.)
 // The big tile pays when it still fills whole 256-CU rounds: rounds x 2 (tile area) x 0.9 (measured gain) against the
 // 160-row rounds.  M=2560: N=16384 -> 2 rounds against 4 (taken); N=12288 -> 2 against 3, N=4096 -> 1 against 1 (not).
 static bool big_tile_pays(int M, int N) {

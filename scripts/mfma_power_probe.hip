@@ -120,6 +120,67 @@ __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ ne
     out[blockIdx.x * NWAVES * 64 + threadIdx.x] = s;
 }
 
+
+// W operand straight from global memory into registers (no LDS write, no LDS read for it): each wave loads its own four
+// 16x32 W fragments per K-sub-step with global_load_dwordx4, three sub-steps ahead; the two waves that share a W column
+// block read the same addresses (the second hits the CU's L1).  A still comes by LDS-DMA (2.5 pieces per wave and K-step)
+// and ds_read_b128.  FAR_W of every 16 W loads and FAR_A of every 5 A pieces come from the far window.
+template <int FAR_A, int FAR_W>
+__global__ __launch_bounds__(512) void feed_direct(const uint4* __restrict__ near_buf, size_t near_bytes, const uint4* __restrict__ far_buf,
+                                                   size_t far_bytes, float* __restrict__ out, int iters) {
+    __shared__ uint4 lds[8192];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = near_buf[(size_t)blockIdx.x * 4096 % (near_bytes / 16 - 4096) + i];
+    __syncthreads();
+    bf16x8 a0[5], a1[5];
+    bf16x8 w[3][4];
+    for (int i = 0; i < 5; i++) { a0[i] = __builtin_bit_cast(bf16x8, lds[(i * 64 + lane) & 4095]); a1[i] = a0[i]; }
+    f32x4 acc[5][4] = {};
+    const size_t nwin = near_bytes / (gridDim.x * 8), fwin = far_bytes / (gridDim.x * 8);
+    const uint64_t nbase = (uint64_t)near_buf + (size_t)(blockIdx.x * 8 + wave) * nwin;
+    const uint64_t fbase = (uint64_t)far_buf + (size_t)(blockIdx.x * 8 + wave) * fwin;
+    // W windows are shared by the wave pair (w, w+4)
+    const uint4* wn_base = near_buf + ((size_t)(blockIdx.x * 4 + (wave & 3)) * (near_bytes / (gridDim.x * 4))) / 16 + lane;
+    const uint4* wf_base = far_buf + ((size_t)(blockIdx.x * 4 + (wave & 3)) * (far_bytes / (gridDim.x * 4))) / 16 + lane;
+    const unsigned wn_win = (unsigned)(near_bytes / (gridDim.x * 4) / 16), wf_win = (unsigned)(far_bytes / (gridDim.x * 4) / 16);
+    unsigned noff = 0, foff = 0, rd = wave * 97, wno = 0, wfo = 0;
+    uint4* sink = lds + 4096 + wave * 512;
+    auto load_w = [&](bf16x8 (&dst)[4], int far) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < far) { dst[j] = *(const bf16x8*)(wf_base + wfo); wfo += 64; if (wfo >= wf_win) wfo = 0; }
+            else         { dst[j] = *(const bf16x8*)(wn_base + wno); wno += 64; if (wno >= wn_win) wno = 0; }
+        }
+    };
+    load_w(w[0], 0); load_w(w[1], 0);
+    for (int it = 0; it < iters; it += 6) {           // 6 K-steps = 12 sub-steps: the three W register sets rotate with static indices
+#pragma unroll
+        for (int ks = 0; ks < 12; ks++) {
+            if ((ks & 1) == 0) {
+#pragma unroll
+                for (int g = 0; g < ((ks & 2) == 0 ? 3 : 2); g++) {
+                    if ((ks & 3) == 0 && g < FAR_A) { glds16_s(fbase + foff, lane * 16, sink + g * 64); foff += 1024; if (foff >= fwin) foff = 0; }
+                    else                            { glds16_s(nbase + noff, lane * 16, sink + (g + 3 * ((ks >> 1) & 1)) * 64); noff += 1024; if (noff >= nwin) noff = 0; }
+                }
+            }
+            bf16x8* cur = (ks & 1) ? a1 : a0;
+            bf16x8* nxt = (ks & 1) ? a0 : a1;
+            rd = (rd + 577) & 4095;
+#pragma unroll
+            for (int i = 0; i < 5; i++) nxt[i] = __builtin_bit_cast(bf16x8, lds[(rd + i * 64 + lane) & 4095]);
+            load_w(w[(ks + 2) % 3], (ks & 3) == 0 ? FAR_W : 0);
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[i]), "v"(w[ks % 3][j]));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 4; j++) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <typename K>
 static void run_feed(const char* name, K kern, const uint4* nb, size_t nbytes, const uint4* fb, size_t fbytes, float* d_out, int iters,
                      int nwaves = 8, double mfma_per_kstep = 40.0) {
@@ -210,6 +271,8 @@ int main() {
         run_feed("320x256, one fragment set/wave    R13/40 G9 far3/18", feed<13, 18, 3, 5, 8, 8, 13, true>, nb, nbytes, fb, fbytes, o2, it2 / 2, 8, 80.0);
         run_feed("160x256, one fragment set/wave    R9 G6.5 far2", feed<9, 13, 2, 5, 4, 8, 9, true>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("reads issued, 3 of 9 unused       R9(6 used) G6.5 far2", feed<9, 13, 2, 5, 4, 8, 6>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("W direct to registers, A by DMA   far A1/5 W3/16", feed_direct<1, 3>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("W direct to registers, all L2 hits", feed_direct<0, 0>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("4 waves x 80x128, MFMA + reads only", feed<13, 0, 0, 5, 8, 4>, nb, nbytes, fb, fbytes, o2, it2, 4, 80.0);
     }
     return 0;
