@@ -278,13 +278,16 @@ def main() -> None:
                            "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
         except Exception:
             pass
-        rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
+        rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel + gemm_bf16_big_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
                                   "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
                                   "launches": gm["launches"], "avg_ms": gm["ms"] / gm["launches"],
                                   # context, not a second roofline: bf16 GEMMs on random data are power-limited on this chip
                                   "power_limited_reference": {"tuned_bf16_gemm_random_data_tflops": 1247.0,
-                                                              "source": "MI355X_MICROARCH.md (DVFS give-back); these binaries on all-zero operands: "
+                                                              "mfma_only_register_loop_random_data_tflops": 2030.0,
+                                                              "same_instruction_mix_synthetic_loop_tflops": {"160x256 tile": 1210.0, "320x256 tile": 1410.0},
+                                                              "source": "MI355X_MICROARCH.md (DVFS give-back); scripts/mfma_power_probe.hip -> "
+                                                                        "profiles/r02_mfma_power_probe.log; these binaries on all-zero operands: "
                                                                         "1433-1542 TF/s (profiles/r02_gemm_zero_vs_random.log)"}}
     if "flash_attn" in fams:
         fa = fams["flash_attn"]

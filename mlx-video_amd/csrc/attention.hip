@@ -452,6 +452,7 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // 256-row tiles fill whole rounds); a 32-row kernel pipelined across 32-key halves 50.5 / 853 us; a fixed s_setprio
   // for the odd wave slot of each SIMD: no change.  PMC of the 64-row form: 35 issue cycles per MFMA (4.7 VALU + 1 LDS
   // read beside it), 18 more parked or stalled - the softmax placement is not what holds the loop at ~55 % MFMA-busy.
+  // Packed fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32, two scores per instruction): 79.1 against 73.8 us at 1280^2.
   // LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
   p.QT = (Tq + 127) / 128;

@@ -5,7 +5,7 @@ import csv, glob, json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 outdir, outjson = sys.argv[1], sys.argv[2]
-SHAPES = {"ff1_gelu": (2560, 16384, 4096), "ff2_gate": (2560, 4096, 16384), "qkv_split": (2560, 12288, 4096), "out_gate": (2560, 4096, 4096),
+SHAPES = {"ff1_gelu": (2560, 16384, 4096), "ff2_gate": (2560, 4096, 16384), "qk_sumsq": (2560, 8192, 4096), "v_transposed": (2560, 4096, 4096), "out_gate": (2560, 4096, 4096),
           "o2_res": (2560, 4096, 4096), "q2": (2560, 4096, 4096), "ctx_kv_split": (2048, 8192, 4096)}
 PASSES = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
           "sq1": ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU"],
@@ -21,7 +21,7 @@ for shape, (M, N, K) in SHAPES.items():
         acc = {}
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for row in csv.DictReader(open(f, newline="")):
-                if "gemm_bf16_kernel" in row["Kernel_Name"]:
+                if "gemm_bf16_" in row["Kernel_Name"]:
                     acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for c, v in acc.items():
             v = v[3:] if len(v) > 3 else v          # skip the warm-up launches
@@ -31,7 +31,7 @@ for shape, (M, N, K) in SHAPES.items():
                    env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
         for row in csv.DictReader(open(f, newline="")):
-            if "gemm_bf16_kernel" in row["Name"]:
+            if "gemm_bf16_" in row["Name"]:
                 vals["avg_ns"], vals["min_ns"], vals["kernel"] = float(row["AverageNs"]), float(row["MinNs"]), row["Name"]
     e = {"M": M, "N": N, "K": K, "kernel": vals.get("kernel"), "counters": vals}
     if "FETCH_SIZE" in vals:
@@ -52,7 +52,7 @@ for shape, (M, N, K) in SHAPES.items():
     res[shape] = e
     print(shape, json.dumps({k: v for k, v in e.items() if k != "counters"}), flush=True)
 from bench import source_sha
-names = {"ff1_gelu": "gemm_bf16_kernel<5,GELU> FF1 M=2560 N=16384 K=4096"}
+names = {"ff1_gelu": "gemm_bf16_big_kernel<GELU> FF1 M=2560 N=16384 K=4096"}
 out = {"source": "rocprofv3 --pmc (one pass per counter set) -- python scripts/prof_gemm.py 3 <shape>; kernel-trace of the same driver; MI355X",
        "correction": "FETCH_SIZE counts 64 B per 128-B L2 read request on gfx950: bytes = 2*FETCH_SIZE KiB; WRITE_SIZE exact; Infinity-Cache hits are counted (L2->fabric traffic)",
        "source_sha": source_sha(),
