@@ -68,7 +68,15 @@ __device__ __forceinline__ void glds16_s(uint64_t base, unsigned lane_off, void*
                  : "=&s"(keep) : "v"(lane_off), "s"(base), "s"(dst) : "memory");
 }
 
-template <int R, int G2, int FAR, int NA = 5, int NB = 4, int NWAVES = 8, int RU = R, bool SINGLE = false>     // G2 = DMA pieces per wave per TWO K-steps
+__device__ unsigned long long g_clk[4];        // block 0: s_memtime / s_memrealtime (100 MHz) before and after the loop
+
+// the same without saving / restoring M0 around each piece (nothing else in the loop reads M0)
+__device__ __forceinline__ void glds16_nosave(uint64_t base, unsigned lane_off, void* lds_dst) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base), "s"(dst) : "memory", "m0");
+}
+
+template <int R, int G2, int FAR, int NA = 5, int NB = 4, int NWAVES = 8, int RU = R, bool SINGLE = false, bool NOSAVE = false>     // G2 = DMA pieces per wave per TWO K-steps
 __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ near_buf, size_t near_bytes, const uint4* __restrict__ far_buf,
                                             size_t far_bytes, float* __restrict__ out, int iters) {
     __shared__ uint4 lds[8192];                       // [0, 64 KiB): fragment source, [64, 128 KiB): DMA sink (8 slots per wave)
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ ne
     const uint64_t fbase = (uint64_t)far_buf + (size_t)(blockIdx.x * NWAVES + wave) * fwin;
     unsigned noff = 0, foff = 0, rd = wave * 97;
     uint4* sink = lds + 4096 + wave * (4096 / NWAVES);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[0] = __builtin_amdgcn_s_memtime(); g_clk[1] = __builtin_amdgcn_s_memrealtime(); }
     for (int it = 0; it < iters; it += 2) {
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {              // 4 sub-steps of K=32 = two K-steps of 64
@@ -109,12 +118,18 @@ __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ ne
         }
 #pragma unroll
         for (int g = 0; g < G2; g++) {
+            if (NOSAVE) {
+                if (g < FAR) { glds16_nosave(fbase + foff, lane * 16, sink + (g % (64 / NWAVES)) * 64); foff += 1024; if (foff >= fwin) foff = 0; }
+                else         { glds16_nosave(nbase + noff, lane * 16, sink + (g % (64 / NWAVES)) * 64); noff += 1024; if (noff >= nwin) noff = 0; }
+                continue;
+            }
             if (g < FAR) { glds16_s(fbase + foff, lane * 16, sink + (g % (64 / NWAVES)) * 64); foff += 1024; if (foff >= fwin) foff = 0; }
             else         { glds16_s(nbase + noff, lane * 16, sink + (g % (64 / NWAVES)) * 64); noff += 1024; if (noff >= nwin) noff = 0; }
         }
         if (G2 > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G2 > 0 ? G2 : 0));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_clk[2] = __builtin_amdgcn_s_memtime(); g_clk[3] = __builtin_amdgcn_s_memrealtime(); }
     float s = 0.f;
     for (int i = 0; i < NA; i++) for (int j = 0; j < NB; j++) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     out[blockIdx.x * NWAVES * 64 + threadIdx.x] = s;
@@ -196,7 +211,14 @@ static void run_feed(const char* name, K kern, const uint4* nb, size_t nbytes, c
         double tf = mfma_per_kstep * 16384 * iters * 256 * nwaves / (ms * 1e-3) / 1e12;
         if (r == 0) continue;
         sum += tf; if (tf > best) best = tf;
-        if (r == reps) printf("%-44s %8.2f ms/launch  mean %7.1f TF/s  best %7.1f TF/s\n", name, ms, sum / reps, best);
+        if (r == reps) {
+            unsigned long long c[4] = {0, 0, 0, 0};
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_clk), sizeof(c));
+            const double ghz = c[3] > c[1] ? (double)(c[2] - c[0]) / (double)(c[3] - c[1]) * 0.1 : 0.0;
+            // cycles one SIMD spends per 40-MFMA K-step of ONE of its two waves' tiles (MFMA alone: 640 per wave)
+            const double cyc = ghz * 1e9 * (ms * 1e-3) / iters;
+            printf("%-44s %8.2f ms/launch  mean %7.1f TF/s  best %7.1f TF/s  clock %.2f GHz  %5.0f cycles per K-step\n", name, ms, sum / reps, best, ghz, cyc);
+        }
     }
 }
 
@@ -274,6 +296,13 @@ int main() {
         run_feed("W direct to registers, A by DMA   far A1/5 W3/16", feed_direct<1, 3>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("W direct to registers, all L2 hits", feed_direct<0, 0>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("4 waves x 80x128, MFMA + reads only", feed<13, 0, 0, 5, 8, 4>, nb, nbytes, fb, fbytes, o2, it2, 4, 80.0);
+        // the same mixes on all-zero data: what the instruction streams sustain when power is not the limit
+        CHECK(hipMemset(nb, 0, nbytes)); CHECK(hipMemset(fb, 0, (size_t)1 << 30));
+        run_feed("ZEROS  MFMA + fragment reads      R9 G0", feed<9, 0, 0>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("ZEROS  + LDS-DMA, all L2 hits     R9 G6.5", feed<9, 13, 0>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("ZEROS  + 2 of 13 miss L2          R9 G6.5 far2", feed<9, 13, 2>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("ZEROS  no M0 save/restore         R9 G6.5 far2", feed<9, 13, 2, 5, 4, 8, 9, false, true>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("ZEROS  320x256 mix                R13/40 G9 far3/18", feed<13, 18, 3, 5, 8, 8, 13, true>, nb, nbytes, fb, fbytes, o2, it2 / 2, 8, 80.0);
     }
     return 0;
 }
