@@ -6,6 +6,9 @@
 #include <stdlib.h>
 #include <utility>
 
+#ifndef LTXK_DEFER_GROUPS
+#define LTXK_DEFER_GROUPS 2   // MFMA groups of a K-step run after the next barrier (gemm_core.h MmaPipe)
+#endif
 #ifndef LTXK_STAGGER
 #define LTXK_STAGGER 0   // measured neutral (profiles/r01 notes); kept for A/B
 #endif
@@ -239,7 +242,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     } else
 #endif
     {
-      MmaPipe<TT, 4, TRANS, 2> pipe;
+      MmaPipe<TT, 4, TRANS, (LTXK_DEFER_GROUPS <= TT ? LTXK_DEFER_GROUPS : TT)> pipe;
       kloop(pipe);
     }
   } else {

@@ -168,8 +168,13 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
 // registers), so they execute while the first fragment reads of the new stage are in flight: the
 // LDS cold start after each barrier (all 8 waves reading at once) no longer idles the matrix pipe.
 // Requires TT >= 2 (both deferred groups then share the ks=1 W fragments).
+// Fragment reads run this many MFMA groups ahead of their use.  1, not 2 (round 2, interleaved A/B on one box,
+// profiles/r02_gemm_prefetch_depth_ab.log): the N=4096 launches 85.5 -> 79.7 us (bias) / 89.7 -> 85.2 us (gate+residual),
+// FF2 299 -> 290 us, the whole block -1.1 %, the VAE decode -0.7 %; 3 is slower than 2.  With two waves per SIMD the
+// other wave covers an LDS read that is one group (64 matrix-pipe cycles) ahead, and the shorter lead leaves fewer
+// reads queued in front of each barrier.
 #ifndef LTXK_PREFETCH_GROUPS
-#define LTXK_PREFETCH_GROUPS 2
+#define LTXK_PREFETCH_GROUPS 1
 #endif
 // DG = number of trailing MFMA groups of a K-step that are deferred past the next barrier (2 <= DG <= TT:
 // all deferred groups use the ks=1 W fragments).  DG=2 hides the LDS cold start; DG=TT additionally puts a
@@ -181,7 +186,11 @@ struct MmaPipe {
   static constexpr int PD = LTXK_PREFETCH_GROUPS;   // fragment reads run PD MFMA groups ahead of their use
   static constexpr int NG = 2 * TT;
   static constexpr int MAXP = G::W_PER_WAVE + G::MAXA;
+#ifdef LTXK_DMA_PER_GROUP
+  static constexpr int PPG = LTXK_DMA_PER_GROUP;                // A/B: bunch the stage's LDS-DMA pieces into the first groups
+#else
   static constexpr int PPG = (MAXP + NG - 1) / NG;
+#endif
   static constexpr int TOTAL = 2 * (4 + TT);
   static_assert(TT >= 2 && DG >= 2 && DG <= TT, "deferred groups must all lie in the ks=1 half");
   // fragment registers persist across K-steps: after step() wf[1][*] and af[1][TT-DG..TT-1] hold the operands

@@ -1,4 +1,4 @@
-"""A/B of two library builds on the whole DiT forward (scripts/ab_step.py, LTXK_FUSE=7), interleaved child processes.
+"""A/B of two library builds on the whole DiT forward (scripts/ab_step.py, LTXK_FUSE=15), interleaved child processes.
 usage: ab_lib.py ROUNDS LAYERS name=path/to/lib.so ..."""
 import json, os, subprocess, sys, collections
 rounds, layers = int(sys.argv[1]), sys.argv[2]
@@ -7,7 +7,7 @@ res = collections.defaultdict(list)
 for r in range(rounds):
     for spec in sys.argv[3:]:
         name, _, path = spec.partition("=")
-        env = dict(os.environ, AB_VARIANTS="7")
+        env = dict(os.environ, AB_VARIANTS=os.environ.get("AB_VARIANTS", "15"))
         if path:
             env["LTXK_LIB"] = os.path.abspath(path)
         out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ab_step.py"), layers, "5"], env=env, capture_output=True, text=True)
