@@ -211,6 +211,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       wait_keep_and_barrier<PER_STAGE + NB + NX2>();
     } else if constexpr (HAS_RES && KC >= 3 && KC < 3 + TT) {
       wait_keep_and_barrier<PER_STAGE + 4>();
+    } else if constexpr (KC == -3) {
+      wait_keep_and_barrier<0>();                                   // last K-step: nothing younger than its own stage is in flight
     } else {
       wait_keep_and_barrier<PER_STAGE>();
     }
@@ -218,11 +220,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     if (kt == 8) LTXK_STAMP(2);
     int s2 = s + 2;
     s2 = s2 >= 3 ? s2 - 3 : s2;
-    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // tail: harmless re-load of the last stage into a free slot
+    const int kt2 = kt + 2 < nk ? kt + 2 : nk - 1;   // short K (no peeled tail): harmless re-load of the last stage into a free slot
+    // KC = -2 / -3: the last two K-steps of a launch long enough to have them peeled request nothing (re-loading the last
+    // stage there kept 2 x 7 pieces in flight past the loop: the epilogue began with a wait for them)
+    auto issue = [&](int i) __attribute__((always_inline)) {
+      if constexpr (KC != -2 && KC != -3) issue_piece(i, kt2, s2);
+    };
     if constexpr (TT >= 2) {
-      pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+      pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, issue);
     } else {
-      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, s2); });
+      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, issue);
     }
     s = s + 1 == 3 ? 0 : s + 1;
   };
@@ -231,7 +238,13 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
       ((I < nk ? kstep(pipe, I, IntC<I>{}) : (void)0), ...);
     }(std::make_integer_sequence<int, PEEL>{});
-    for (int kt = PEEL; kt < nk; ++kt) kstep(pipe, kt, IntC<-1>{});
+    const bool tail = nk >= PEEL + 2;
+    const int nmain = tail ? nk - 2 : nk;
+    for (int kt = PEEL; kt < nmain; ++kt) kstep(pipe, kt, IntC<-1>{});
+    if (tail) {
+      kstep(pipe, nk - 2, IntC<-2>{});
+      kstep(pipe, nk - 1, IntC<-3>{});
+    }
     if constexpr (TT >= 2) pipe.finish(acc);
   };
   if constexpr (TT >= 2) {
@@ -572,13 +585,14 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int q = 0; q < 8; ++q) af[i][q] = (bf16)0.f;
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](int kt, auto last_c) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value != 0;    // the last K-step requests nothing
     // stage kt has landed in every wave's view, and every wave has finished reading the other slot (stage kt-1)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int slot = kt & 1;
     const char* wb = smem + slot * BIG_STAGE + (wn * 128) * 128 + frow;
     const char* ab = smem + slot * BIG_STAGE + BIG_STAGE_W + (wm * 80) * 128 + frow;
-    const int kt1 = kt + 1 < nk ? kt + 1 : nk - 1;                // tail: harmless re-load of the last stage
+    const int kt1 = kt + 1;
     // K-sub-step 0 fragments.  The W fragments whose registers are free first, then the held-back columns, each of their
     // last MFMAs freeing one A fragment register for the new stage, then the remaining W fragments.
 #pragma unroll
@@ -609,13 +623,17 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
         if (ks == 0) {
           af[i] = *(const bf16x8*)(ab + i * 2048 + koff1);        // row i done: its A fragment register is free
           // next stage's LDS-DMA: all nine pieces in the first three MFMA rows, so they have most of a K-step to land
+          if constexpr (!LAST) {
 #pragma unroll
-          for (int q = 0; q < LTXK_BIG_PPR; ++q) issue_piece(i * LTXK_BIG_PPR + q, kt1, slot ^ 1);   // (no-op past piece 8)
+            for (int q = 0; q < LTXK_BIG_PPR; ++q) issue_piece(i * LTXK_BIG_PPR + q, kt1, slot ^ 1);   // (no-op past piece 8)
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-  }
+  };
+  for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, IntC<0>{});
+  kstep(nk - 1, IntC<1>{});
 #pragma unroll
   for (int i = 0; i < 5; ++i)
 #pragma unroll
