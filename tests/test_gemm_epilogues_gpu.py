@@ -69,10 +69,10 @@ BIG_SHAPES = [(320, 256, 64), (2560, 1024, 256), (700, 512, 192), (2560, 4096, 1
 def test_gemm_320x256_tile_equals_160x256_tile(dev, M, N, K, monkeypatch):
     """The 320x256-tile kernel (gemm.hip, taken for FF1-sized launches) walks K in the same order with the same MFMA as
     the 160x256 one: forced on (LTXK_GEMM_BIG=2) it must give the same bits, for every epilogue it supports, with and
-    without bias, with a ragged last row tile (M=700, 1296) and when its output is a strided view."""
+    without bias, with a ragged last row tile (M=700, 1296), a strided A (lda = K + 64) and when its output is a strided view."""
     from mlx_video_amd import ops
     g = torch.Generator(device=dev).manual_seed(M * 3 + N + K)
-    a = torch.randn((M, K), generator=g, device=dev).to(BF)
+    a = torch.randn((M, K + 64), generator=g, device=dev).to(BF)[:, :K]          # row stride lda = K + 64
     w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(BF)
     b = (torch.randn(N, generator=g, device=dev) * 0.1).to(BF)
     for epi in (0, 1, 2):
