@@ -360,7 +360,9 @@ class LTXModel:
         if ctx_kv is None:                  # text K / V^T of the current block, recomputed every forward (one buffer set)
             # (computing block li+1's text K / V^T on a side stream beside block li - they do not depend on the token
             # stream - measured 1.7 % SLOWER eagerly and unchanged in a captured graph: the main kernels leave no CU idle
-            # long enough for a 156-KiB-LDS GEMM workgroup; profiles/r02_launch_structure_ab.log)
+            # long enough for a 156-KiB-LDS GEMM workgroup; profiles/r02_launch_structure_ab.log.  k's q_norm + RoPE on a side
+            # stream beside the V^T GEMM - a memory-bound kernel that needs no LDS - measured the same way: 1.269 against
+            # 1.264 ms per block.  Forked graph branches cost more than they overlap.)
             kv_buf = (torch.empty((B * S, D), dtype=BF16, device=dev),
                       torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev),
                       torch.empty((B * S, D // 64), dtype=torch.float32, device=dev))
