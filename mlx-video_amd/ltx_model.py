@@ -362,7 +362,9 @@ class LTXModel:
             # stream - measured 1.7 % SLOWER eagerly and unchanged in a captured graph: the main kernels leave no CU idle
             # long enough for a 156-KiB-LDS GEMM workgroup; profiles/r02_launch_structure_ab.log.  k's q_norm + RoPE on a side
             # stream beside the V^T GEMM - a memory-bound kernel that needs no LDS - measured the same way: 1.269 against
-            # 1.264 ms per block.  Forked graph branches cost more than they overlap.)
+            # 1.264 ms per block.  Forked graph branches cost more than they overlap.  Nor does one GRID for two independent GEMMs
+            # (q|k on 320x256 tiles with v's 160x256 tiles back-filling behind them; text k|v with q2): 1269.6 us per block
+            # either way, big tiles first or last - the tail of one launch is not where the time goes.)
             kv_buf = (torch.empty((B * S, D), dtype=BF16, device=dev),
                       torch.zeros((B, D, sp64), dtype=BF16, device=dev) if sp64 != S else torch.empty((B, D, sp64), dtype=BF16, device=dev),
                       torch.empty((B * S, D // 64), dtype=torch.float32, device=dev))

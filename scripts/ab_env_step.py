@@ -25,6 +25,7 @@ graphs, outs = {}, {}
 for name, env in variants:
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    model.fuse = int(env.get("LTXK_FUSE", os.environ.get("LTXK_FUSE_DEFAULT", "15")))       # read at construction otherwise
     for _ in range(2):
         o = model.forward_tokens(lat, plan, ctx, pe)
     torch.cuda.synchronize()
