@@ -453,6 +453,10 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // for the odd wave slot of each SIMD: no change.  PMC of the 64-row form: 35 issue cycles per MFMA (4.7 VALU + 1 LDS
   // read beside it), 18 more parked or stalled - the softmax placement is not what holds the loop at ~55 % MFMA-busy.
   // Packed fp32 softmax arithmetic (v_pk_fma_f32 / v_pk_add_f32, two scores per instruction): 79.1 against 73.8 us at 1280^2.
+  // The short last round as a launch of its own with 8-wave workgroups (64 rows, 128-KiB ring, each 32-row group's four waves
+  // splitting the keys four ways - halves of every tile x even / odd tiles): 80.1 against 73.4 us at 1280^2, 65.5 against 58.2 at
+  // 1280x1024 - and without any tail split the launch takes 74.9 us: two workgroups on a CU share its matrix pipe, so the
+  // short round's lone workgroups already run nearly twice as fast, and there is little left for a finer split to win.
   // LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
   static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
   p.QT = (Tq + 127) / 128;
