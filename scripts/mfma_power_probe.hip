@@ -70,13 +70,21 @@ __device__ __forceinline__ void glds16_s(uint64_t base, unsigned lane_off, void*
 
 __device__ unsigned long long g_clk[4];        // block 0: s_memtime / s_memrealtime (100 MHz) before and after the loop
 
+// the same piece through the buffer path: base in a 4-SGPR resource (raw buffer, 0x00020000 = gfx9 data format 32 bit), one
+// 32-bit VGPR offset; M0 as above
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void blds16(i32x4 rsrc, unsigned off, void* lds_dst) {
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(off), "s"(rsrc), "s"(dst) : "memory", "m0");
+}
+
 // the same without saving / restoring M0 around each piece (nothing else in the loop reads M0)
 __device__ __forceinline__ void glds16_nosave(uint64_t base, unsigned lane_off, void* lds_dst) {
     const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(lane_off), "s"(base), "s"(dst) : "memory", "m0");
 }
 
-template <int R, int G2, int FAR, int NA = 5, int NB = 4, int NWAVES = 8, int RU = R, bool SINGLE = false, bool NOSAVE = false>     // G2 = DMA pieces per wave per TWO K-steps
+template <int R, int G2, int FAR, int NA = 5, int NB = 4, int NWAVES = 8, int RU = R, bool SINGLE = false, bool NOSAVE = false, bool BUF = false>     // G2 = DMA pieces per wave per TWO K-steps
 __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ near_buf, size_t near_bytes, const uint4* __restrict__ far_buf,
                                             size_t far_bytes, float* __restrict__ out, int iters) {
     __shared__ uint4 lds[8192];                       // [0, 64 KiB): fragment source, [64, 128 KiB): DMA sink (8 slots per wave)
@@ -118,6 +126,14 @@ __global__ __launch_bounds__(NWAVES * 64) void feed(const uint4* __restrict__ ne
         }
 #pragma unroll
         for (int g = 0; g < G2; g++) {
+            if (BUF) {
+                i32x4 rs;
+                const uint64_t bb = g < FAR ? fbase : nbase;
+                rs[0] = (int)(unsigned)bb; rs[1] = (int)(unsigned)(bb >> 32) & 0xffff; rs[2] = -1; rs[3] = 0x00020000;
+                if (g < FAR) { blds16(rs, foff + lane * 16, sink + (g % (64 / NWAVES)) * 64); foff += 1024; if (foff >= fwin) foff = 0; }
+                else         { blds16(rs, noff + lane * 16, sink + (g % (64 / NWAVES)) * 64); noff += 1024; if (noff >= nwin) noff = 0; }
+                continue;
+            }
             if (NOSAVE) {
                 if (g < FAR) { glds16_nosave(fbase + foff, lane * 16, sink + (g % (64 / NWAVES)) * 64); foff += 1024; if (foff >= fwin) foff = 0; }
                 else         { glds16_nosave(nbase + noff, lane * 16, sink + (g % (64 / NWAVES)) * 64); noff += 1024; if (noff >= nwin) noff = 0; }
@@ -302,6 +318,7 @@ int main() {
         run_feed("ZEROS  + LDS-DMA, all L2 hits     R9 G6.5", feed<9, 13, 0>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("ZEROS  + 2 of 13 miss L2          R9 G6.5 far2", feed<9, 13, 2>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("ZEROS  no M0 save/restore         R9 G6.5 far2", feed<9, 13, 2, 5, 4, 8, 9, false, true>, nb, nbytes, fb, fbytes, o2, it2);
+        run_feed("ZEROS  pieces by buffer_load lds  R9 G6.5 far2", feed<9, 13, 2, 5, 4, 8, 9, false, false, true>, nb, nbytes, fb, fbytes, o2, it2);
         run_feed("ZEROS  320x256 mix                R13/40 G9 far3/18", feed<13, 18, 3, 5, 8, 8, 13, true>, nb, nbytes, fb, fbytes, o2, it2 / 2, 8, 80.0);
     }
     return 0;
