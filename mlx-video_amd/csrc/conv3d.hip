@@ -200,6 +200,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     constexpr int KC = decltype(kc)::value;                 // K-step index relative to kbeg in the peeled steps, -1 in the loop
     if constexpr (KC == 0 || KC == 1) wait_keep_and_barrier<PER_STAGE + NB>();
     else if constexpr (HAS_RES && KC >= 3 && KC < 3 + TT) wait_keep_and_barrier<PER_STAGE + 4>();
+    else if constexpr (KC == -3) wait_keep_and_barrier<0>();   // last K-step: nothing younger than its own stage is in flight
     else wait_keep_and_barrier<PER_STAGE>();
     if constexpr (HAS_RES && KC >= 2 && KC < 2 + TT) load_res_band(IntC<(KC >= 2 ? KC - 2 : 0)>{});
     int s2 = s + 2;
@@ -213,13 +214,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
       kt2 = nk - 1;
     }
     const int cb = pcb;
-    pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) { issue_piece(i, kt2, cb, s2); });
+    // KC = -2 / -3: the last two K-steps of a range long enough to have them peeled request nothing (as in gemm.hip)
+    pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, [&](int i) {
+      if constexpr (KC != -2 && KC != -3) issue_piece(i, kt2, cb, s2);
+    });
     s = s + 1 == 3 ? 0 : s + 1;
   };
   [&]<int... I>(std::integer_sequence<int, I...>) __attribute__((always_inline)) {
     ((kbeg + I < nk ? kstep(kbeg + I, IntC<I>{}) : (void)0), ...);
   }(std::make_integer_sequence<int, PEEL>{});
-  for (int kt = kbeg + PEEL; kt < nk; ++kt) kstep(kt, IntC<-1>{});
+  const bool tail = nk - kbeg >= PEEL + 2;
+  const int nmain = tail ? nk - 2 : nk;
+  for (int kt = kbeg + PEEL; kt < nmain; ++kt) kstep(kt, IntC<-1>{});
+  if (tail) {
+    kstep(nk - 2, IntC<-2>{});
+    kstep(nk - 1, IntC<-3>{});
+  }
   pipe.finish(acc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (!SPLIT) {
