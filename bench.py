@@ -275,7 +275,12 @@ def main() -> None:
                 k = next(v for n, v in pm["kernels"].items() if "FF1" in n)
                 traffic = {"bytes_per_launch": k["read_bytes_corrected"] + k["write_bytes"], "algorithmic_bytes": k["algorithmic_bytes"],
                            "kernel": "FF1 GEMM M=2560 N=16384 K=4096", "source_sha": pm["source_sha"],
-                           "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+                           "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+                           # same passes: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock held, per launch shape
+                           "mfma_busy_frac_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["mfma_busy_frac_of_simd_cycles"], 3)
+                                                       for n, v in pm["kernels"].items() if "mfma_busy_frac_of_simd_cycles" in v},
+                           "clock_GHz_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["clock_GHz_profiled"], 2)
+                                                  for n, v in pm["kernels"].items() if v.get("clock_GHz_profiled")}}
         except Exception:
             pass
         rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel + gemm_bf16_big_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
