@@ -504,17 +504,19 @@ static int pick_tt(int M, int N) {
 
 }  // namespace ltxk
 
-// ---- 320 x 256 tile for the widest Linear (FF1: M=2560, N=16384) ------------------------------------------------------
-// These launches run at the chip's power limit, and what an MFMA costs in energy besides itself is mostly the L2 -> LDS
-// stream that feeds it (scripts/mfma_power_probe.hip: the 160x256 kernel's instruction mix sustains 1.21-1.24 PF in a
-// synthetic loop, the kernel itself 1.1-1.2; the mix of a 320x256 tile sustains 1.41).  Doubling the tile takes 31 % off
-// the LDS-DMA bytes per MFMA, 22 % off the L2 -> fabric bytes (8x4 patches of 320-row tiles) and, with 80x128 per wave,
-// 28 % off the fragment reads.  The price is registers: 160 accumulator registers per lane at two waves per SIMD leave
-// room for ONE set of operand fragments, so a wave reads, waits and multiplies (the SIMD's other wave covers the wait),
-// refilling each fragment register as soon as its last MFMA of the K-sub-step has issued; and LDS holds two stages, not
-// three, so a stage's LDS-DMA pieces are all issued in the first MFMA groups of the step before it.
-// The accumulators live in VGPRs (gfx950's register file is unified; a kernel that names AGPRs gets its 256-register
-// budget split 128 / 128 by hipcc, which 160 accumulators do not fit): the MFMAs are inline asm, accumulating in place.  Only launches that fill whole rounds use it (dispatch below).
+// ---- 320 x 256 tile: FF1 (M=2560, N=16384), self-attention q|k (N=8192), the text k|v pair (M=2048) --------------------
+// What keeps the matrix pipe of the 160x256 kernel at ~60 % busy is the CU's one LDS: every 1-KiB fragment read (4 cycles
+// at 256 B/clk) and every 1-KiB LDS-DMA piece (8 cycles at 128 B/clk) is LDS time the MFMAs overlap only in part, and on
+// random data the chip holds ~1.8 GHz instead of 2.4 on top (scripts/mfma_power_probe.hip, DESIGN.md §5b: that kernel's
+// instruction mix sustains 1.25 PF in a barrier-free synthetic loop, the kernel itself 1.1-1.2; the mix of a 320x256 tile
+// sustains 1.44).  Doubling the tile takes 31 % off the LDS-DMA bytes per MFMA, 22 % off the L2 -> fabric bytes (8x4 patches
+// of 320-row tiles) and, with 80x128 per wave, 28 % off the fragment reads.  The price is registers: 160 accumulator
+// registers per lane at two waves per SIMD leave room for ONE set of operand fragments, so a wave reads, waits and
+// multiplies (the SIMD's other wave covers the wait), refilling each fragment register as soon as its last MFMA of the
+// K-sub-step has issued; and LDS holds two stages, not three, so a stage's LDS-DMA pieces are all issued in the first MFMA
+// rows of the step before it.  The accumulators live in VGPRs (gfx950's register file is unified; a kernel that names AGPRs
+// gets its 256-register budget split 128 / 128 by hipcc, which 160 accumulators do not fit): the MFMAs are inline asm,
+// accumulating in place.  Only launches that fill whole rounds use it (big_tile_pays below).  Same bits as the 160x256 kernel.
 namespace ltxk {
 
 constexpr int BIG_BM = 320, BIG_BN = 256;
