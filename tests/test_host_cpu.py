@@ -292,7 +292,8 @@ def test_gemm_tile_order_is_a_bijection(tmp_path):
 #include <vector>
 int main() {
   const int cfgs[][2] = {{16,16},{16,64},{16,48},{16,32},{8,16},{24,48},{16,80},{13,16},{16,112},{32,16},{5,3},{16,24},{1,1},{7,128},
-                         {33,16},{41,32},{16,96},{8,48},{2,16},{40,2},{11,64}};
+                         {33,16},{41,32},{16,96},{8,48},{2,16},{40,2},{11,64},
+                         /* 320-row tile grids: FF1, q|k, text k|v at M=2560 / 2048, FF1 at M=5184 / 6656 */ {8,64},{8,32},{7,32},{17,64},{21,64},{3,4}};
   for (auto& c : cfgs) {
     const int RT = c[0], CT = c[1];
     std::vector<int> seen(RT * CT, 0);
