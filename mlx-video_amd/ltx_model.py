@@ -318,8 +318,10 @@ class LTXModel:
         if cos.dim() == 4:
             cos, sin = cos[0], sin[0]
         cos, sin = cos.contiguous(), sin.contiguous()
-        tok2row = plan.tok2row
         U = plan.values.numel()
+        # one timestep row for every token (an unconditioned CFG pair): no per-token row gather - the kernels then skip a
+        # dependent load in front of every modulation / gate read
+        tok2row = plan.tok2row if (U > 1 or os.environ.get("LTXK_TOK2ROW_ALWAYS") == "1") else None      # (env: A/B runs)
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)
 
         # --- prepare (ltx.py:129-158) ---
