@@ -35,4 +35,5 @@ timeit("torch copy_ (bf16)", lambda i: y.copy_(xs[i % 8]))
 timeit("torch mul scalar (bf16)", lambda i: torch.mul(xs[i % 8], 1.5, out=y))
 timeit("ltxk rmsnorm_modulate (self-reducing)", lambda i: ops.rmsnorm_modulate(xs[i % 8], 1e-6, ada[:, 1], ada[:, 0], 6 * D, row, out=y))
 timeit("ltxk rmsnorm_modulate (carried statistics)", lambda i: ops.rmsnorm_modulate(xs[i % 8], 1e-6, ada[:, 1], ada[:, 0], 6 * D, row, out=y, sumsq=ss, scale_is_one_plus=True))
+timeit("ltxk rmsnorm_modulate (carried, one mod row)", lambda i: ops.rmsnorm_modulate(xs[i % 8], 1e-6, ada[:, 1], ada[:, 0], 6 * D, None, out=y, sumsq=ss, scale_is_one_plus=True))
 timeit("ltxk rmsnorm (no modulation, carried)", lambda i: ops.rmsnorm_modulate(xs[i % 8], 1e-6, out=y, sumsq=ss))
