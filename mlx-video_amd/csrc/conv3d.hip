@@ -26,6 +26,7 @@ struct ConvParams {
   // fused PixelNorm (+ modulation) + SiLU of the output row (needs Cout == BN: the tile holds whole rows)
   bf16* act_out; const bf16* act_scale; const bf16* act_shift; float act_eps; int act_silu; int rows_per_batch;
   int xcd_order;        // A/B switch (LTXK_CONV_XCD, default 1)
+  int m_base;           // first voxel row of this launch (the short last round runs as a second launch of half-height tiles)
 };
 
 template <int TT, int WN, bool RES, bool SPLIT>
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
     tile = p.xcd_order ? x * q + (x < r ? x : r) + j : (int)blockIdx.x;
   }
   const int ct = tile % p.CT, rt = tile / p.CT;
-  const int m0 = rt * G::BM, n0 = ct * G::BN;
+  const int m0 = p.m_base + rt * G::BM, n0 = ct * G::BN;
   const int K = p.ntaps * p.Cin;
 
   const int lrow = lane >> 3;
@@ -390,6 +391,26 @@ __global__ void conv_splitk_finalize_kernel(const float* __restrict__ slab, cons
 }
 
 template <int TT, int WN, bool RES>
+static int conv_launch_plain(const ConvParams& p, hipStream_t stream) {
+  using G = GemmGeom<TT, WN>;
+  auto kern = conv3d_k3_kernel<TT, WN, RES, false>;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_conv3d_k3_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
+  LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16");
+  return LTXK_OK;
+}
+
+template <int TT, int WN, bool RES>
 static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspace, size_t workspace_bytes) {
   using G = GemmGeom<TT, WN>;
   ConvParams p = p0;
@@ -426,22 +447,25 @@ static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspac
     LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16(finalize)");
     return LTXK_OK;
   }
-  auto kern = conv3d_k3_kernel<TT, WN, RES, false>;
-  static thread_local int attr_dev = -1;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev != attr_dev) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) {
-      ltxk_set_error("ltxk_conv3d_k3_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      return LTXK_ELAUNCH;
-    }
-    attr_dev = dev;
-  }
   p.slab = nullptr; p.S = 1; p.kper = nk;
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(GEMM_THREADS), G::LDS_BYTES, stream, p);
-  LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16");
-  return LTXK_OK;
+  // The 128-channel stage at 33x128x128 voxels is 2112 tiles of 256 rows = 8.25 rounds of 256 CUs: the quarter round takes
+  // as long as a whole one.  Its rows run as a second launch of 128-row tiles instead (twice the workgroups, half the work
+  // each): 8 rounds + half a round of half tiles.
+  if constexpr (TT == 4 && WN == 2) {
+    const int tail_env = [] { const char* e = getenv("LTXK_CONV_TAIL"); return e ? atoi(e) : 1; }();   // 0: off (A/B, tests; read per call)
+    const int rem = tiles % 256;
+    if (tail_env && p.CT == 1 && tiles > 256 && rem > 0 && rem <= 128) {
+      ConvParams pm = p;
+      pm.RT = tiles - rem;
+      int rc = conv_launch_plain<TT, WN, RES>(pm, stream);
+      if (rc != LTXK_OK) return rc;
+      ConvParams pt = p;
+      pt.m_base = (tiles - rem) * G::BM;
+      pt.RT = (p.M - pt.m_base + 127) / 128;
+      return conv_launch_plain<2, 2, RES>(pt, stream);
+    }
+  }
+  return conv_launch_plain<TT, WN, RES>(p, stream);
 }
 
 }  // namespace ltxk
@@ -467,6 +491,7 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.act_out = (bf16*)a->act_out; p.act_scale = (const bf16*)a->act_scale; p.act_shift = (const bf16*)a->act_shift;
   p.act_eps = a->act_eps; p.act_silu = a->act_silu; p.rows_per_batch = a->D * a->H * a->W;
   { const char* e = getenv("LTXK_CONV_XCD"); p.xcd_order = e ? atoi(e) : 1; }
+  p.m_base = 0;
   if (a->act_out) {
     LTXK_CHECK_ARG(a->Cout == 128 || a->Cout == 256, "ltxk_conv3d_k3_bf16: the fused norm/activation output needs Cout == 128 or 256 (got %d)", a->Cout);
     LTXK_CHECK_ARG((a->act_scale == nullptr) == (a->act_shift == nullptr), "ltxk_conv3d_k3_bf16: act_scale and act_shift must both be set or both NULL");

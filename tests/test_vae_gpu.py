@@ -304,3 +304,23 @@ def test_on_frames_ready_covers_89_frames(dev):
     assert out.shape == (1, 3, 89, 128, 128)
     assert seen == set(range(89)) and len(calls) >= 2          # streamed in more than one piece, nothing twice
     assert sum(n for _, n in calls) == 89
+
+
+@pytest.mark.parametrize("res", [False, True])
+def test_conv3d_short_last_round_as_half_tiles(dev, res, monkeypatch):
+    """128-channel conv on 3x160x160 voxels = 300 tiles of 256 rows: the 44 tiles past the whole 256-CU round run as a
+    second launch of 128-row tiles (conv3d.hip, LTXK_CONV_TAIL).  Every output row is still one K-ordered sum: same bits as
+    the single launch, with and without the residual."""
+    from mlx_video_amd import video_vae as V
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn((1, 3, 160, 160, 128), generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn((128, 3, 3, 3, 128), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    b = (torch.randn(128, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    r = torch.randn((1, 3, 160, 160, 128), generator=g, device=dev).to(torch.bfloat16) if res else None
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LTXK_CONV_TAIL", mode)
+        outs[mode] = V.conv3d(x, w, b, True, 0, resid=r)
+        torch.cuda.synchronize()
+    assert torch.equal(outs["0"], outs["1"])
+    assert float(outs["1"].float().abs().mean()) > 0.05
