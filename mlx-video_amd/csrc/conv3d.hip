@@ -448,21 +448,27 @@ static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspac
     return LTXK_OK;
   }
   p.slab = nullptr; p.S = 1; p.kper = nk;
-  // The 128-channel stage at 33x128x128 voxels is 2112 tiles of 256 rows = 8.25 rounds of 256 CUs: the quarter round takes
-  // as long as a whole one.  Its rows run as a second launch of 128-row tiles instead (twice the workgroups, half the work
-  // each): 8 rounds + half a round of half tiles.
-  if constexpr (TT == 4 && WN == 2) {
+  // A short last round takes as long as a whole one: the 128-channel stage at 33x128x128 voxels is 2112 tiles of 256 rows =
+  // 8.25 rounds of 256 CUs, the 512-channel stage 7.2, the 256-channel stage 27.2.  The rows past the last whole round run as
+  // a second launch of lower tiles (128 instead of 256 rows, 96 instead of 160): more workgroups, less work each - a
+  // fraction of a round instead of one.  Every output row is still the same K-ordered sum: same bits.
+  if constexpr ((TT == 4 && WN == 2) || (TT == 5 && WN == 4)) {
+    constexpr int TTT = TT == 4 ? 2 : 3;                          // tail tile height in 16-row MFMA blocks per wave row
+    using GT = GemmGeom<TTT, WN>;
     const int tail_env = [] { const char* e = getenv("LTXK_CONV_TAIL"); return e ? atoi(e) : 1; }();   // 0: off (A/B, tests; read per call)
-    const int rem = tiles % 256;
-    if (tail_env && p.CT == 1 && tiles > 256 && rem > 0 && rem <= 128) {
+    const int rem_rt = (tiles % 256) / p.CT;                      // whole row tiles past the last whole round
+    const int rt_main = p.RT - rem_rt;
+    const long tail_rows = (long)p.M - (long)rt_main * G::BM;
+    const long tail_tiles = (tail_rows + GT::BM - 1) / GT::BM * p.CT;
+    if (tail_env && tiles > 256 && rem_rt > 0 && rt_main > 0 && (long)rt_main * p.CT % 256 < p.CT && tail_tiles <= 256) {
       ConvParams pm = p;
-      pm.RT = tiles - rem;
+      pm.RT = rt_main;
       int rc = conv_launch_plain<TT, WN, RES>(pm, stream);
       if (rc != LTXK_OK) return rc;
       ConvParams pt = p;
-      pt.m_base = (tiles - rem) * G::BM;
-      pt.RT = (p.M - pt.m_base + 127) / 128;
-      return conv_launch_plain<2, 2, RES>(pt, stream);
+      pt.m_base = rt_main * G::BM;
+      pt.RT = (int)((tail_rows + GT::BM - 1) / GT::BM);
+      return conv_launch_plain<TTT, WN, RES>(pt, stream);
     }
   }
   return conv_launch_plain<TT, WN, RES>(p, stream);

@@ -306,17 +306,19 @@ def test_on_frames_ready_covers_89_frames(dev):
     assert sum(n for _, n in calls) == 89
 
 
+@pytest.mark.parametrize("cout,shape", [(128, (3, 160, 160)), (256, (3, 128, 128)), (512, (2, 112, 112))])
 @pytest.mark.parametrize("res", [False, True])
-def test_conv3d_short_last_round_as_half_tiles(dev, res, monkeypatch):
-    """128-channel conv on 3x160x160 voxels = 300 tiles of 256 rows: the 44 tiles past the whole 256-CU round run as a
-    second launch of 128-row tiles (conv3d.hip, LTXK_CONV_TAIL).  Every output row is still one K-ordered sum: same bits as
-    the single launch, with and without the residual."""
+def test_conv3d_short_last_round_as_half_tiles(dev, res, cout, shape, monkeypatch):
+    """Convs whose tile count ends in a short round of 256 CUs - 128 channels on 3x160x160 voxels = 300 tiles of 256 rows,
+    256 channels on 3x128x128 = 308 tiles of 160 rows, 512 channels on 2x112x112 = 157 x 2 tiles: the rows past the last
+    whole round run as a second launch of lower tiles (conv3d.hip, LTXK_CONV_TAIL).  Every output row is still one K-ordered
+    sum: same bits as the single launch, with and without the residual."""
     from mlx_video_amd import video_vae as V
-    g = torch.Generator(device=dev).manual_seed(3)
-    x = torch.randn((1, 3, 160, 160, 128), generator=g, device=dev).to(torch.bfloat16)
-    w = (torch.randn((128, 3, 3, 3, 128), generator=g, device=dev) * 0.02).to(torch.bfloat16)
-    b = (torch.randn(128, generator=g, device=dev) * 0.1).to(torch.bfloat16)
-    r = torch.randn((1, 3, 160, 160, 128), generator=g, device=dev).to(torch.bfloat16) if res else None
+    g = torch.Generator(device=dev).manual_seed(3 + cout)
+    x = torch.randn((1,) + shape + (128,), generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn((cout, 3, 3, 3, 128), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    b = (torch.randn(cout, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    r = torch.randn((1,) + shape + (cout,), generator=g, device=dev).to(torch.bfloat16) if res else None
     outs = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("LTXK_CONV_TAIL", mode)
