@@ -2,7 +2,8 @@
 """bench.py — LTX-2 19B dev denoise step (512x512x33, CFG 4.0, bf16) + video-VAE decode on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; started without a
+  launcher, `--gpus N` starts its own N ranks from a parent that never touches the GPU, or exits non-zero)
 
 One "step" = the whole body of denoise_dev's loop (mlx_video/generate.py:1227-1304) at
 BASELINE.json configs[1]: latent (1,128,5,16,16) -> N=1280 tokens, 48 blocks, D=4096, text
@@ -83,6 +84,69 @@ def cpu_baseline_block(threads: int):
             "sample": f"{REPS} of 48 DiT blocks (oracle fp32, B=2 CFG pair, N=1280, S=1024, D=4096) = {dt * REPS:.1f} s, scaled x48/{REPS}"}
 
 
+def time_forward(model, B: int, N: int, reps: int = 3, dev=None):
+    """Median ms of ONE DiT forward (all L blocks + prepare + head, text K/V recomputed) at batch B, N tokens per row, as a
+    captured-graph replay.  Used for the one-GPU prediction of the CFG-pair split: a pair rank runs the B=1 forward."""
+    from mlx_video_amd.ltx_model import TimestepPlan, precompute_freqs_cis
+    from mlx_video_amd.schedulers import create_position_grid
+    g = torch.Generator(device=dev).manual_seed(7)
+    lat = torch.randn((B, N, 128), generator=g, device=dev).to(torch.bfloat16)
+    ctx = torch.randn((B, 1024, 3840), generator=g, device=dev).to(torch.bfloat16)
+    pos = create_position_grid(1, N // 256, 16, 16).to(dev)
+    pe = precompute_freqs_cis(pos, 4096, 10000.0, (20, 2048, 2048), 32)
+    plan = TimestepPlan(torch.tensor([0.7], device=dev).to(torch.bfloat16), torch.zeros(B * N, dtype=torch.int32, device=dev))
+    for _ in range(2):
+        model.forward_tokens(lat, plan, ctx, pe)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        model.forward_tokens(lat, plan, ctx, pe)
+    gr.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        gr.replay()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    del gr
+    return sorted(ts)[len(ts) // 2]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no RANK in the environment): this parent - which
+    never touches the GPU - starts the N ranks itself (one child process per GPU, the same environment torchrun would give
+    them), relays rank 0's JSON line and exits with the first non-zero child code.  It never prints a line of its own, so an
+    N-GPU request cannot come back as an n_gpus=1 measurement."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("LTXK_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU runtime on this image
+    if have < n and not rehearsal:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) are visible; refusing to measure fewer", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    if rc == 0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    else:
+        print(f"[bench] a rank failed (exit code {rc}); no result line", file=sys.stderr)
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,10 +163,12 @@ def main() -> None:
     ap.add_argument("--cache-context", action="store_true", help="reuse ctx K/V across steps (reported separately)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # LTXK_BENCH_REHEARSAL=1 (builder's one-GPU box only): all ranks share cuda:0 and talk over gloo, to execute the N>1
     # code paths of this file without an 8-GPU node; numbers from such a run are not throughput measurements.
@@ -164,13 +230,18 @@ def main() -> None:
 
     try:
         run_steps(max(args.warmup, 1) if not args.no_graph else args.warmup)      # W untimed steps (>= 1: builds the step graph)
-    except RuntimeError as e:          # a failed capture must not cost the measurement: fall back to eager launches, and say so
-        if args.no_graph:
+    except RuntimeError as e:
+        # Only a CAPTURE failure may fall back to eager launches (a failed capture must not cost the measurement); a kernel
+        # fault also surfaces as RuntimeError and must end the run - a headline from a poisoned context is worthless.
+        msg = str(e).lower()
+        if args.no_graph or not any(w in msg for w in ("capture", "captur", "graph")):
             raise
         print(f"[bench] step-graph capture failed ({e}); eager launches", file=sys.stderr, flush=True)
-        torch.cuda.synchronize()
         args.no_graph = True
         graph_cache.clear()
+        probe = torch.ones(1024, device=dev)
+        if float((probe * 2).sum().item()) != 2048.0:            # the context must still compute (and synchronise) correctly
+            raise SystemExit("[bench] GPU context unhealthy after the failed capture")
         run_steps(args.warmup)
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks ----
     barrier()
@@ -234,6 +305,24 @@ def main() -> None:
         except Exception as e:           # the secondary line must never cost the primary one
             cfgpair = {"error": repr(e)[:300]}
 
+
+    # ---- one-GPU prediction of the CFG-pair split (N=1 only): a pair rank runs ONE B=1 forward per step where this
+    # rank runs the B=2 forward; expected 2-GPU efficiency of the split = t(B=2) / (2 * t(B=1)), before any RCCL cost.
+    # Plus the 2-seed batch (B=4, M=5120: every N=4096 launch then fills whole rounds of 320x256 tiles) as an EXTRA line.
+    cfgpair_pred = None
+    batch2 = None
+    if world == 1 and args.layers == 48 and os.environ.get("LTXK_BENCH_EXTRAS", "1") != "0":
+        try:
+            cfgpair_pred = {}
+            for n_tok in (1280, 3328):
+                t1, t2 = time_forward(model, 1, n_tok, dev=dev), time_forward(model, 2, n_tok, dev=dev)
+                cfgpair_pred[f"N{n_tok}"] = {"forward_b1_ms": t1, "forward_b2_ms": t2, "cfgpair_predicted_efficiency": t2 / (2.0 * t1)}
+            t4 = time_forward(model, 4, 1280, dev=dev)
+            batch2 = {"forward_b4_ms": t4, "steps_per_s_two_seeds_batched": 2.0 / (t4 * 1e-3),
+                      "vs_two_sequential_b2_forwards": 2.0 * cfgpair_pred["N1280"]["forward_b2_ms"] / t4,
+                      "note": "two seeds' CFG pairs as ONE B=4 forward (M=5120), forward only (no step tail); reported beside, never instead of, the B=2 headline"}
+        except Exception as e:
+            cfgpair_pred = {"error": repr(e)[:300]}
 
     seeds = world if pg_shard is None else max(world // 2, 1)
     steps_per_s = seeds * args.steps / dt
@@ -315,6 +404,13 @@ def main() -> None:
     result["kernel_source_sha"] = source_sha()
     if cfgpair is not None:
         result["cfgpair"] = cfgpair
+    if cfgpair_pred is not None:
+        result["cfgpair_one_gpu_prediction"] = cfgpair_pred
+        if "N1280" in cfgpair_pred:
+            result["forward_b1_ms"] = cfgpair_pred["N1280"]["forward_b1_ms"]
+            result["cfgpair_predicted_efficiency"] = cfgpair_pred["N1280"]["cfgpair_predicted_efficiency"]
+    if batch2 is not None:
+        result["two_seed_batch"] = batch2
 
     if not args.no_vae:
         try:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LTXK_VERSION 200
+#define LTXK_VERSION 300
 
 #define LTXK_OK 0
 #define LTXK_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
@@ -93,11 +93,16 @@ int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
  *   q  : (B,Tq,H*128) bf16 row stride ldq        k : (B,Tk,H*128) bf16 row stride ldk
  *   vt : (B,H*128,ldvt) bf16 = V transposed, ldvt >= Tk rounded up to 64, multiple of 8, pad columns finite
  *   out: (B,Tq,H*128) bf16 row stride ldo
- * q, k, vt, out 16-byte aligned; ldq, ldk, ldo multiples of 8.  Environment switches for A/B runs (read by the
- * library, never required): LTXK_FA_SPLIT=0 disables the key-split of the short last round of workgroups
- * (results then do not depend on how many (batch, head) pairs share a launch), LTXK_FA_XCD=0 the XCD-local
- * tile order, LTXK_FA_VARIANT={4,5,8} selects a kernel form.
+ * q, k, vt, out 16-byte aligned; ldq, ldk, ldo multiples of 8; scale > 0.
+ * Rounding points (oracle/dit.py::sdpa, "flash" policy): S = q.k^T in fp32; P = exp2(fma(S, scale*log2 e, -M)) with M an
+ * INTEGER row offset, so bf16(P) does not depend on the tiling; l = sum P in fp32; O = bf16((bf16(P) @ V) / l).
  * ------------------------------------------------------------------------------------- */
+enum {
+  /* The query tiles of the short last round of workgroups are normally split over two workgroups that halve the keys
+   * and merge (O, M, l): faster, but those rows then sum their keys in another order than in a launch whose grid has no
+   * short round.  With this flag the result for a (batch, head) does not depend on how many share a launch.           */
+  LTXK_ATTN_NO_TAIL_SPLIT = 1
+};
 typedef struct ltxk_attn_args {
   const void* q; const void* k; const void* vt; void* out;
   int32_t ldq, ldk, ldvt, ldo;
@@ -114,6 +119,7 @@ typedef struct ltxk_attn_args {
   const float* cos;
   const float* sin;
   float eps;
+  int32_t flags;               /* LTXK_ATTN_* */
 } ltxk_attn_args;
 
 int ltxk_flash_attn(const ltxk_attn_args* args, void* stream);

@@ -31,7 +31,7 @@ class AttnArgs(Structure):
         ("ldq", c_int32), ("ldk", c_int32), ("ldvt", c_int32), ("ldo", c_int32),
         ("B", c_int32), ("H", c_int32), ("Tq", c_int32), ("Tk", c_int32), ("scale", c_float),
         ("q_sumsq", c_void_p), ("q_sumsq_ld", c_int32), ("q_sumsq_n", c_int32),
-        ("q_norm_weight", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("eps", c_float),
+        ("q_norm_weight", c_void_p), ("cos", c_void_p), ("sin", c_void_p), ("eps", c_float), ("flags", c_int32),
     ]
 
 
@@ -100,29 +100,52 @@ SIGNATURES = {
 }
 
 _lib = None
+AB_LIB_PATH = os.path.join(_HERE, "libltxk_ab.so")
+ATTN_NO_TAIL_SPLIT = 1        # ltxk.h: LTXK_ATTN_NO_TAIL_SPLIT
 
 
-def load() -> ctypes.CDLL:
-    """Load libltxk.so; raise LtxkError with the build recipe if it is not there."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str) -> ctypes.CDLL:
+    if not os.path.exists(path):
         raise LtxkError(
-            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            f"{path} is missing: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C mlx-video_amd/csrc`). "
             "There is no CPU fallback for the product path.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
     for which, st in enumerate((GemmArgs, Conv3dArgs, AttnArgs)):
         if lib.ltxk_abi_sizeof(which) != ctypes.sizeof(st):
-            raise LtxkError(f"{LIB_PATH} is stale: sizeof({st.__name__}) is {lib.ltxk_abi_sizeof(which)} in the library, "
+            raise LtxkError(f"{path} is stale: sizeof({st.__name__}) is {lib.ltxk_abi_sizeof(which)} in the library, "
                             f"{ctypes.sizeof(st)} in this binding; rebuild it (make -C mlx-video_amd/csrc)")
-    _lib = lib
     return lib
+
+
+def load() -> ctypes.CDLL:
+    """Load libltxk.so; raise LtxkError with the build recipe if it is not there."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+class use_library:
+    """``with use_library(AB_LIB_PATH):`` routes every ops call inside the block to another build of the same ABI - the
+    -DLTXK_AB measurement build, whose launch-form switches are environment variables (csrc/common.h).  For scripts/ and
+    for the tests that compare two launch forms of one kernel bit for bit; the product path never enters it."""
+
+    def __init__(self, path: str = AB_LIB_PATH):
+        self.lib = _open(path)
+
+    def __enter__(self):
+        global _lib
+        self.prev, _lib = _lib, self.lib
+        return self.lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.prev
 
 
 def check(rc: int, what: str) -> None:

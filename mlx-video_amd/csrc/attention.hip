@@ -16,7 +16,6 @@
 // V is consumed transposed (V^T: [d][key], key-contiguous); the V projection GEMM writes it
 // in that layout directly (ltxk_gemm_bf16 out_tokens_per_batch).
 #include "common.h"
-#include <stdlib.h>
 
 namespace ltxk {
 
@@ -192,7 +191,7 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 16; ++j) o[i][j] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float mc_run = -1e30f, l_run = 0.f;   // running offset (exp2 domain, integer-valued once set), running sum
 
   const int nt = (p.Tk + FA_BK - 1) / FA_BK;
 #pragma unroll
@@ -290,18 +289,24 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
     // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
     // tile's P is exponentiated after the decision and the previous tile's P.V is complete, so everything
     // scaled against the old max is rescaled exactly once.
-    if (__any((mx - m_run) * p.c > FA_DEFER)) {
+    // The offset is kept as an INTEGER in the exp2 domain (mc_run = ceil(max * c) at the time it was last raised):
+    // bf16(exp2(x - M)) = 2^-M * bf16(exp2(x)) exactly for integer M, so the bf16 rounding of every P does not depend
+    // on which tile's running max it was taken against, alpha below is an exact power of two, and the whole kernel
+    // differs from  O = (bf16(P) @ V) / sum(P),  P = exp2(fma(S, c, -M))  by fp32 summation order only - whatever the
+    // tile size, the deferral or the key split of the tail workgroups (oracle/dit.py::sdpa, "flash" policy).
+    const float mxc = mx * p.c;
+    if (__any(mxc - mc_run > FA_DEFER)) {
       asm volatile("" ::: "memory");       // keeps this a real branch: hipcc otherwise if-converts it into 64 multiplies + selects per tile
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.c);
-      m_run = m_new;
+      const float m_new = fmaxf(mc_run, __builtin_ceilf(mxc));
+      const float alpha = __builtin_amdgcn_exp2f(mc_run - m_new);
+      mc_run = m_new;
       l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int j = 0; j < 16; ++j) o[db][j] *= alpha;
     }
-    const float mc = m_run * p.c;
+    const float mc = mc_run;
     float psum = 0.f;
     bf16x8 pb[NKB][2];
 #pragma unroll
@@ -339,14 +344,14 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
       for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int j = 0; j < 16; ++j) xo[(db * 16 + j) * 64 + lane] = o[db][j];
-      xo[4096 + lane] = m_run;
+      xo[4096 + lane] = mc_run;
       xo[4096 + 64 + lane] = l_tot;
     }
     __syncthreads();
     if (kh == 1) return;
     const float m1 = xo[4096 + lane], l1 = xo[4096 + 64 + lane];
-    const float m = fmaxf(m_run, m1);
-    const float a0 = __builtin_amdgcn_exp2f((m_run - m) * p.c), a1 = __builtin_amdgcn_exp2f((m1 - m) * p.c);
+    const float m = fmaxf(mc_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(mc_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);      // exact powers of two
     l_tot = l_tot * a0 + l1 * a1;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -417,6 +422,7 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   const float scale = a->scale;
   LTXK_CHECK_ARG(q && k && vt && out, "ltxk_flash_attn_bf16: null pointer");
   LTXK_CHECK_ARG(B > 0 && H > 0 && Tq > 0 && Tk > 0, "ltxk_flash_attn_bf16: bad dims");
+  LTXK_CHECK_ARG(scale > 0.f, "ltxk_flash_attn_bf16: scale must be positive");
   LTXK_CHECK_ARG(ldq >= H * FA_DH && ldk >= H * FA_DH && ldo >= H * FA_DH, "ltxk_flash_attn_bf16: row strides < H*128");
   LTXK_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "ltxk_flash_attn_bf16: row strides must be multiples of 8");
   const int tk_pad = (Tk + FA_BK - 1) / FA_BK * FA_BK;
@@ -457,15 +463,14 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // splitting the keys four ways - halves of every tile x even / odd tiles): 80.1 against 73.4 us at 1280^2, 65.5 against 58.2 at
   // 1280x1024 - and without any tail split the launch takes 74.9 us: two workgroups on a CU share its matrix pipe, so the
   // short round's lone workgroups already run nearly twice as fast, and there is little left for a finer split to win.
-  // LTXK_FA_XCD={1,0} and LTXK_FA_SPLIT={1,0} remain for A/B runs.
-  static const int xcd_map = [] { const char* e = getenv("LTXK_FA_XCD"); return e ? atoi(e) : 1; }();
+  // LTXK_FA_XCD={1,0} remains in the A/B build.
+  const int xcd_map = LTXK_AB_INT("LTXK_FA_XCD", 1);
   p.QT = (Tq + 127) / 128;
   p.xcd = (xcd_map && (B * H) % 8 == 0) ? 1 : 0;
-  // read per call (not cached) so one process can A/B it: with the split on, a tile in the short round sums its
-  // keys in a different order than the same rows would in a launch without a short round (e.g. B=1 vs B=2), so
-  // batching changes low-order bits; LTXK_FA_SPLIT=0 restores batch-invariant results.
-  const char* split_env = getenv("LTXK_FA_SPLIT");
-  const int split = split_env ? atoi(split_env) : 1;
+  // With the tail split on, a tile in the short round sums its keys in a different order than the same rows would in a
+  // launch without a short round (e.g. B=1 vs B=2), so batching changes low-order bits; LTXK_ATTN_NO_TAIL_SPLIT in
+  // args->flags restores batch-invariant results (an explicit ABI field because it changes output bits).
+  const int split = (a->flags & LTXK_ATTN_NO_TAIL_SPLIT) ? 0 : 1;
   static thread_local int slots = 0;
   if (slots == 0) {
     int cus = 256;

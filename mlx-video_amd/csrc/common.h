@@ -14,6 +14,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define LTXK_WAVE 64
 
+// A/B switches.  The product library (libltxk.so) reads NO environment variable and keeps no mutable global state
+// (include/ltxk.h, Conventions): LTXK_AB_INT(name, default) is the constant `default` there.  The measurement build
+// (`make ab` -> libltxk_ab.so, -DLTXK_AB; loaded only by scripts/ and by the tests that compare two launch forms of one
+// kernel bit for bit, through mlx_video_amd._lib.use_library) reads the named variable on every call.
+#ifdef LTXK_AB
+#include <stdlib.h>
+#define LTXK_AB_INT(name, dflt) ([] { const char* e__ = getenv(name); return e__ ? atoi(e__) : (dflt); }())
+#else
+#define LTXK_AB_INT(name, dflt) (dflt)
+#endif
+
 // Thread-local error string (never throws across the ABI).
 void ltxk_set_error(const char* fmt, ...);
 

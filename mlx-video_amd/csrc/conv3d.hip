@@ -455,7 +455,7 @@ static int conv_launch(const ConvParams& p0, hipStream_t stream, float* workspac
   if constexpr ((TT == 4 && WN == 2) || (TT == 5 && WN == 4)) {
     constexpr int TTT = TT == 4 ? 2 : 3;                          // tail tile height in 16-row MFMA blocks per wave row
     using GT = GemmGeom<TTT, WN>;
-    const int tail_env = [] { const char* e = getenv("LTXK_CONV_TAIL"); return e ? atoi(e) : 1; }();   // 0: off (A/B, tests; read per call)
+    const int tail_env = LTXK_AB_INT("LTXK_CONV_TAIL", 1);        // 0: off (A/B build only)
     const int rem_rt = (tiles % 256) / p.CT;                      // whole row tiles past the last whole round
     const int rt_main = p.RT - rem_rt;
     const long tail_rows = (long)p.M - (long)rt_main * G::BM;
@@ -496,7 +496,7 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   p.ntaps = a->taps_d == 1 ? 9 : 27; p.kd0 = a->taps_d == 1 ? 1 : 0;
   p.act_out = (bf16*)a->act_out; p.act_scale = (const bf16*)a->act_scale; p.act_shift = (const bf16*)a->act_shift;
   p.act_eps = a->act_eps; p.act_silu = a->act_silu; p.rows_per_batch = a->D * a->H * a->W;
-  { const char* e = getenv("LTXK_CONV_XCD"); p.xcd_order = e ? atoi(e) : 1; }
+  p.xcd_order = LTXK_AB_INT("LTXK_CONV_XCD", 1);
   p.m_base = 0;
   if (a->act_out) {
     LTXK_CHECK_ARG(a->Cout == 128 || a->Cout == 256, "ltxk_conv3d_k3_bf16: the fused norm/activation output needs Cout == 128 or 256 (got %d)", a->Cout);

@@ -445,7 +445,7 @@ extern "C" int ltxk_rmsnorm_modulate_ss(const void* x, void* y, int32_t M, int32
   LTXK_CHECK_ARG((scale == nullptr) == (shift == nullptr), "%s: scale and shift must both be set or both NULL", name);
   LTXK_CHECK_ARG(!scale || mod_stride % 8 == 0, "%s: mod_stride must be a multiple of 8", name);
   // 16-byte chunks per lane: 2 (rows cut into 1024-element pieces) when D allows, else 1
-  static const int ch_env = [] { const char* e = getenv("LTXK_NORM_CH"); return e ? atoi(e) : 0; }();   // A/B runs only
+  const int ch_env = LTXK_AB_INT("LTXK_NORM_CH", 0);
   int ch = (D % 1024 == 0) ? 2 : 1;
   if ((ch_env == 1 || ch_env == 2 || ch_env == 4 || ch_env == 8) && D % (512 * ch_env) == 0) ch = ch_env;
   const int wpr = D / (512 * ch);

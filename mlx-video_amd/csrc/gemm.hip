@@ -358,7 +358,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
         // the wave's 64 columns of row m: 16 values per lane, then the four lanes sharing (lane & 15); fixed order
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
-        if (lane < 16) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
+        // (a wave whose 64-column block lies past N - the last column tile when N % 256 != 0 - has nothing to report:
+        // its slot would be the next row's first partial)
+        if (lane < 16 && n0 + wn * 64 < p.N) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
       }
     }
     if (p.wide) {
@@ -837,18 +839,18 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.gate_stride = a->gate_stride; p.T = (trans || split) ? a->out_tokens_per_batch : 1; p.alpha = a->alpha;
   p.out2 = (bf16*)a->out2; p.n_split = split ? a->n_split : 0; p.ldo2 = a->ldo2;
   p.sumsq = a->sumsq; p.sumsq_ld = a->sumsq_ld;
-  static const int wide_env = [] { const char* e = getenv("LTXK_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  const int wide_env = LTXK_AB_INT("LTXK_GEMM_WIDE", 1);
   // not for the GELU epilogue: its direct stores already issue under the activation arithmetic, and staging
   // them behind it measured 2 % slower on FF1
   p.wide = (!trans && wide_env && a->epilogue != LTXK_EPI_BIAS_GELU && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0) ? 1 : 0;
-  static const int tt_env = [] { const char* e = getenv("LTXK_GEMM_TT"); return e ? atoi(e) : 0; }();   // A/B runs only
+  const int tt_env = LTXK_AB_INT("LTXK_GEMM_TT", 0);
   const int tt = (tt_env >= 1 && tt_env <= 5) ? tt_env : pick_tt(a->M, a->N);
   const int bm = 32 * tt;
   p.RT = (a->M + bm - 1) / bm;
   p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
   hipStream_t st = (hipStream_t)stream;
-  // 0: off, 2: whenever legal (tests); read per call so that one process can compare both forms
-  const int big_env = [] { const char* e = getenv("LTXK_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  // 0: off, 2: whenever legal (A/B build only: tests compare both tiles bit for bit)
+  const int big_env = LTXK_AB_INT("LTXK_GEMM_BIG", 1);
   const bool big_legal = a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
                          (a->epilogue == LTXK_EPI_BIAS || ((a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU) && !a->sumsq));
   if (big_legal && tt_env == 0 && (big_env == 2 || (big_env == 1 && big_tile_pays(a->M, a->N)))) {

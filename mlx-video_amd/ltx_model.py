@@ -18,7 +18,6 @@ Data layout in HBM (per GPU, bf16 unless noted):
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -123,7 +122,7 @@ class ContextKV:
 class LTXModel:
     """Velocity model.  ``model(video=Modality(...)) -> (velocity (B,N,128), None)``."""
 
-    def __init__(self, config: LTXModelConfig, weights: Dict[str, torch.Tensor]):
+    def __init__(self, config: LTXModelConfig, weights: Dict[str, torch.Tensor], fuse: int = 15):
         self.config = config
         self.inner_dim = config.inner_dim
         self.num_attention_heads = config.num_attention_heads
@@ -138,7 +137,12 @@ class LTXModel:
         #   8: self-attention q|k and v as TWO launches after all - q|k (N=8192) then fills exactly one round of the
         #   320x256-tile kernel, 152 + 74 us against 239 us for the one q|k|v launch on 160x256 tiles at M=2560
         #   (profiles/r02_gemm_big_tile_ab.log); the text k|v pair stays one launch (it takes the big tile as it is)
-        self.fuse = int(os.environ.get("LTXK_FUSE", "15"))
+        self.fuse = int(fuse)
+        # every token through the token->row map even when all tokens share one timestep row (A/B runs only)
+        self.tok2row_always = False
+        # ops.flash_attn(tail_split=): False makes a forward's bits independent of the batch it runs in (B=1 per CFG-pair
+        # rank == row b of the B=2 cfg_batch forward), at ~5 % of attention time at N=1280 (attention.hip)
+        self.attn_tail_split = True
         self._pack(weights)
 
     # ------------------------------------------------------------------ weights
@@ -258,8 +262,8 @@ class LTXModel:
         return W
 
     @classmethod
-    def random_init(cls, config: LTXModelConfig, device, seed: int = 1234) -> "LTXModel":
-        return cls(config, cls.random_weights(config, device, seed))
+    def random_init(cls, config: LTXModelConfig, device, seed: int = 1234, fuse: int = 15) -> "LTXModel":
+        return cls(config, cls.random_weights(config, device, seed), fuse=fuse)
 
     # ------------------------------------------------------------------ forward
     def _prepare_context(self, context: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -303,11 +307,14 @@ class LTXModel:
         return kv
 
     def forward_tokens(self, latent: torch.Tensor, plan: TimestepPlan, context: torch.Tensor,
-                       pe: Tuple[torch.Tensor, torch.Tensor], ctx_kv: Optional[ContextKV] = None) -> torch.Tensor:
+                       pe: Tuple[torch.Tensor, torch.Tensor], ctx_kv: Optional[ContextKV] = None,
+                       hidden: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
         """latent (B,N,128) bf16; context (B,S,3840) bf16; pe = (cos,sin) each (1|B,H,N,64) fp32
         (one table shared by every batch row, as in cfg_batch where it is a broadcast,
         generate.py:1196-1202).  ``ctx_kv``: a ContextKV of THIS context (prepare_context); without it the
-        caption projection and the text K/V are recomputed here, as the reference does every forward."""
+        caption projection and the text K/V are recomputed here, as the reference does every forward.
+        ``hidden``: a list that receives a copy of the residual stream (B,N,D) after every block (the reference's
+        debug taps, transformer.py; used by the per-layer parity tests)."""
         cfg = self.config
         D, H, eps = self.inner_dim, self.num_attention_heads, cfg.norm_eps
         B, N, C = latent.shape
@@ -321,7 +328,7 @@ class LTXModel:
         U = plan.values.numel()
         # one timestep row for every token (an unconditioned CFG pair): no per-token row gather - the kernels then skip a
         # dependent load in front of every modulation / gate read
-        tok2row = plan.tok2row if (U > 1 or os.environ.get("LTXK_TOK2ROW_ALWAYS") == "1") else None      # (env: A/B runs)
+        tok2row = plan.tok2row if (U > 1 or self.tok2row_always) else None
         scale = 1.0 / math.sqrt(cfg.attention_head_dim)
 
         # --- prepare (ltx.py:129-158) ---
@@ -372,6 +379,7 @@ class LTXModel:
                       torch.empty((B * S, D // 64), dtype=torch.float32, device=dev))
 
         fq, fs, fp = self.fuse & 1, self.fuse & 2, (self.fuse & 6) == 6
+        ts_ = self.attn_tail_split
         s_x, s_qk, s_q2 = (xss, qkss, q2ss) if fs else (None, None, None)
         for li, blk in enumerate(self.blocks):
             mod = mods[li]                                           # (U,6,D): shift, 1+scale, gate x2
@@ -387,10 +395,10 @@ class LTXModel:
             if fp:
                 ops.qknorm_rope(qk[:, D:], 1, D, blk.wkn, cos, sin, N, H, eps, sumsq=qkss[:, P:])
                 ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale, q_sumsq=qkss, q_norm_weight=blk.wqn,
-                               cos=cos, sin=sin, eps=eps)
+                               cos=cos, sin=sin, eps=eps, tail_split=ts_)
             else:
                 ops.qknorm_rope(qk, 2, D, blk.wqkn, cos, sin, N, H, eps, sumsq=s_qk)
-                ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale)
+                ops.flash_attn(qk[:, :D], qk[:, D:], vt, att, B, H, N, N, scale, tail_split=ts_)
             ops.gemm(att, blk.wo, blk.bo, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
                      gate=mod[:, 2], gate_row=tok2row, gate_stride=ms, sumsq=s_x)
             # text cross-attention (transformer.py:257-261)
@@ -398,16 +406,18 @@ class LTXModel:
             ops.gemm(nx, blk.wq2, blk.bq2, out=q2, sumsq=s_q2)
             kv = ctx_kv.kv[li] if ctx_kv is not None else self._context_kv(blk, ctx, B, S, sp64, kv_buf)
             if fp:
-                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, q_sumsq=q2ss, q_norm_weight=blk.wqn2, eps=eps)
+                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, q_sumsq=q2ss, q_norm_weight=blk.wqn2, eps=eps, tail_split=ts_)
             else:
                 ops.qknorm_rope(q2, 1, D, blk.wqn2, None, None, N, H, eps, sumsq=s_q2)
-                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale)
+                ops.flash_attn(q2, kv[0], kv[1], att, B, H, N, S, scale, tail_split=ts_)
             ops.gemm(att, blk.wo2, blk.bo2, epilogue=ops.EPI_BIAS_RES, out=x, resid=x, sumsq=s_x)
             # feed-forward (transformer.py:343-347)
             ops.rmsnorm_modulate(x, eps, mod[:, 4], mod[:, 3], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
             ops.gemm(nx, blk.w1, blk.b1, epilogue=ops.EPI_BIAS_GELU, out=hff)
             ops.gemm(hff, blk.w2, blk.b2, epilogue=ops.EPI_BIAS_GATE_RES, out=x, resid=x,
                      gate=mod[:, 5], gate_row=tok2row, gate_stride=ms, sumsq=s_x)
+            if hidden is not None:
+                hidden.append(x.reshape(B, N, D).clone())
 
         # --- output head (ltx.py:432-457) ---
         ops.layernorm_modulate(x, eps, head[:, 1], head[:, 0], 2 * D, tok2row, out=nx)

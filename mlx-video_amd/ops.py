@@ -114,10 +114,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
 def flash_attn(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, B: int, H: int,
                Tq: int, Tk: int, scale: float, q_sumsq: Optional[torch.Tensor] = None,
                q_norm_weight: Optional[torch.Tensor] = None, cos: Optional[torch.Tensor] = None,
-               sin: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+               sin: Optional[torch.Tensor] = None, eps: float = 1e-6, tail_split: bool = True) -> torch.Tensor:
     """q (B*Tq, >=H*128) view, k (B*Tk, ...) view, vt (B, H*128, ldvt), out (B*Tq, H*128).  With ``q_sumsq``
-    (B*Tq, >= H*2) the raw q projection is normalised (q_norm_weight) and rotated (cos/sin (H,Tq,64)) inside the kernel."""
+    (B*Tq, >= H*2) the raw q projection is normalised (q_norm_weight) and rotated (cos/sin (H,Tq,64)) inside the kernel.
+    ``tail_split=False``: LTXK_ATTN_NO_TAIL_SPLIT (results independent of how many (batch, head) pairs share the launch)."""
     a = AttnArgs()
+    a.flags = 0 if tail_split else _lib.ATTN_NO_TAIL_SPLIT
     a.q, a.k, a.vt, a.out = _p(q), _p(k), _p(vt), _p(out)
     a.ldq, a.ldk, a.ldvt, a.ldo = q.stride(0), k.stride(0), vt.stride(-2), out.stride(0)
     a.B, a.H, a.Tq, a.Tk, a.scale = B, H, Tq, Tk, scale

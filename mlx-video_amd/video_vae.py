@@ -11,7 +11,6 @@ padded copies), and the norm/activation kernels are one-row-per-voxel streams.
 """
 from __future__ import annotations
 
-import os
 
 import ctypes
 import math
@@ -92,10 +91,10 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, causal: bool, pad_
 def conv_act_fusable(Cout: int, voxels: int, force: bool = False) -> bool:
     """The conv epilogue can carry the following PixelNorm + SiLU when its tile holds whole rows (Cout 128 / 256) and the
     launch would not be split along K anyway (more than 128 tiles: the small 1024 / 512-channel volumes keep split-K).
-    OFF by default (LTXK_VAE_FUSE_ACT=1 turns it on): measured on the 33x512x512 decode, same box, interleaved -
+    OFF by default (``LTX2VideoDecoder.fuse_act = True`` turns it on): measured on the 33x512x512 decode, same box, interleaved -
     12.34 ms separate vs 12.47 ms fused: the normalisation's ~25 VALU per element cost the MFMA kernel's serial epilogue
     0.77 ms, more than the 0.66 ms the HBM-bound PixelNorm launches took beside nothing (profiles/r02_vae_fusion_ab.log)."""
-    if (os.environ.get("LTXK_VAE_FUSE_ACT", "0") != "1" and not force) or Cout not in (128, 256):
+    if not force or Cout not in (128, 256):
         return False
     bm = 256 if Cout <= 128 else 160
     return (voxels + bm - 1) // bm > 128
@@ -331,6 +330,7 @@ class LTX2VideoDecoder:
         self.patch_size = patch_size
         self.decode_noise_scale = 0.025
         self.decode_timestep = 0.05
+        self.fuse_act = False          # PixelNorm + SiLU in the conv epilogues (conv_act_fusable): built, verified, slower
         need = ["conv_in.conv.weight", "conv_out.conv.weight", "up_blocks.1.conv.weight", "latents_mean", "latents_std"]
         missing = [k for k in need if k not in self.W]
         if missing:
@@ -416,7 +416,7 @@ class LTX2VideoDecoder:
                 # PixelNorm + SiLU ride in the epilogue of the conv that produces their input where the tile holds whole
                 # rows (128 / 256 channels): conv1 then writes ONLY its normalised output, conv2 writes the residual
                 # stream and, for the next block, its normalised copy.
-                fuse = conv_act_fusable(c, x.numel() // c)          # off by default: measured slower, see conv_act_fusable
+                fuse = conv_act_fusable(c, x.numel() // c, force=self.fuse_act)    # off by default: measured slower, see conv_act_fusable
                 h_next = None
                 for li in range(nl):
                     rp = f"{pre}.res_blocks.{li}"

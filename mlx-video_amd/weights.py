@@ -115,6 +115,21 @@ def vae_decoder_weights(raw: Dict[str, torch.Tensor], device) -> Dict[str, torch
     return out
 
 
+# Per-channel statistics tensors the reference loads, by exact name (decoder.py:667-690, encoder.py:141-157).  A PyTorch
+# LTX-2 checkpoint also carries `channel`, `mean-of-stds`, `mean-of-stds_over_std-of-means` (convert.py:277-286 skips them)
+# and an `audio_vae.per_channel_statistics.*` pair of the same shape: none of those may land on the video VAE's mean / std.
+_STATS_PREFIXES = ("vae.per_channel_statistics.", "per_channel_statistics.")
+_STATS_NAMES = {"mean-of-means": "mean", "mean": "mean", "std-of-means": "std", "std": "std"}
+
+
+def _stats_kind(k: str) -> Optional[str]:
+    """'mean' / 'std' for the video VAE's statistics tensors, None for every other key."""
+    for pre in _STATS_PREFIXES:
+        if k.startswith(pre):
+            return _STATS_NAMES.get(k[len(pre):])
+    return None
+
+
 def _vae_decoder_key(k: str) -> Optional[str]:
     from .video_vae import LTX2VideoDecoder
     kk = k
@@ -123,18 +138,34 @@ def _vae_decoder_key(k: str) -> Optional[str]:
             kk = kk[len(pre):]
             break
     else:
-        if "per_channel_statistics" in k or k in ("latents_mean", "latents_std"):
-            kk = k.split("vae.")[-1]
-        else:
+        if k in ("latents_mean", "latents_std"):
+            return k
+        kind = _stats_kind(k)
+        if kind is None:
             return None
+        # keep the checkpoint's own name so that _alias_stats applies the reference's precedence
+        # (per_channel_statistics.mean / .std override *-of-means, decoder.py:676-689)
+        return "per_channel_statistics." + k.rsplit(".", 1)[-1]
     return LTX2VideoDecoder.remap_decoder_key(kk)
 
 
 def _alias_stats(out: Dict[str, torch.Tensor]) -> None:
+    """The chain of `if key in weights` assignments of decoder.py:676-695: *-of-means first, plain per_channel_statistics
+    .mean / .std override them, explicit latents_mean / latents_std override both."""
+    explicit = {d: out[d] for d in ("latents_mean", "latents_std") if d in out}
     for src, dst in (("per_channel_statistics.mean-of-means", "latents_mean"), ("per_channel_statistics.std-of-means", "latents_std"),
                      ("per_channel_statistics.mean", "latents_mean"), ("per_channel_statistics.std", "latents_std")):
-        if src in out and dst not in out:
+        if src in out:
             out[dst] = out[src]
+    out.update(explicit)
+
+
+def _resolve_encoder_stats(out: Dict[str, torch.Tensor]) -> None:
+    """encoder.py:141-157: plain `mean` / `std` override the *-of-means tensors, whatever the order in the file."""
+    for kind in ("mean", "std"):
+        of = out.pop(f"per_channel_statistics.{kind}#of-means", None)
+        if of is not None and f"per_channel_statistics.{kind}" not in out:
+            out[f"per_channel_statistics.{kind}"] = of
 
 
 def _vae_encoder_key(k: str) -> Optional[str]:
@@ -143,11 +174,11 @@ def _vae_encoder_key(k: str) -> Optional[str]:
         if k.startswith(pre):
             kk = k[len(pre):]
     if kk is None:
-        if "per_channel_statistics" in k:
-            last = k.split(".")[-1]                      # "mean-of-means" / "std-of-means" (also plain "mean" / "std")
-            kk = "per_channel_statistics." + ("std" if last.startswith("std") else "mean")
-        else:
+        kind = _stats_kind(k)
+        if kind is None:
             return None
+        # "-of-means" names first, plain "mean"/"std" override them (encoder.py:141-157): see vae_encoder_weights
+        return "per_channel_statistics." + kind + ("" if k.rsplit(".", 1)[-1] in ("mean", "std") else "#of-means")
     kk = kk.replace(".conv.conv.", ".conv.").replace("conv_in.conv.", "conv_in.").replace("conv_out.conv.", "conv_out.")
     return kk.replace(".conv1.conv.", ".conv1.").replace(".conv2.conv.", ".conv2.")
 
@@ -159,6 +190,7 @@ def vae_encoder_weights(raw: Dict[str, torch.Tensor], device) -> Dict[str, torch
         kk = _vae_encoder_key(k)
         if kk is not None:
             out[kk] = _to_dev(_conv_to_mlx(kk, v), device)
+    _resolve_encoder_stats(out)
     return out
 
 
@@ -238,7 +270,7 @@ def load_pipeline_modules(model_repo: str, device, need_encoder: bool = False, n
                 tshapes[tk] = meta["shape"]
             ek = _vae_encoder_key(k)
             if ek is not None:
-                enc_keys.append(ek)
+                enc_keys.append(ek.replace("#of-means", ""))
     if has_quant:
         raise ValueError("pre-quantised MLX checkpoints (.scales/.biases) are not supported: MLX affine quantisation is out of scope "
                          "(SURVEY.md §2a); use bf16 weights")
@@ -263,6 +295,7 @@ def load_pipeline_modules(model_repo: str, device, need_encoder: bool = False, n
             if ek is not None:
                 ew[ek] = _to_dev(_conv_to_mlx(ek, v), device)
     _alias_stats(dw)
+    _resolve_encoder_stats(ew)
     mods = {"transformer_weights": tw, "transformer_config": tcfg}
     if build_transformer:
         w = tw

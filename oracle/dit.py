@@ -27,6 +27,10 @@ Tensor = torch.Tensor
 class Prec:
     emulate_bf16: bool = False
     dtype: torch.dtype = torch.float32
+    # sdpa rounding policy.  False: the softmax weights P stay fp32 until after P.V ("fp32 inside, one rounding", what
+    # MLX documents for mx.fast.scaled_dot_product_attention).  True ("flash"): P is rounded to bf16 before P.V, as every
+    # MFMA flash-attention kernel must do to feed the matrix cores - see sdpa() for the exact rounding points.
+    flash_sdpa: bool = False
 
     def r(self, x: Tensor) -> Tensor:
         """Round to bf16 storage (if emulating) and return in the compute dtype."""
@@ -38,6 +42,7 @@ class Prec:
 F32 = Prec(False, torch.float32)
 F64 = Prec(False, torch.float64)
 BF16 = Prec(True, torch.float32)
+BF16_FLASH = Prec(True, torch.float32, flash_sdpa=True)
 
 
 @dataclass(frozen=True)
@@ -207,6 +212,20 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, heads: int, p: Prec) -> Tensor:
     qh = q.reshape(b, tq, heads, dh).transpose(1, 2).to(p.dtype)
     kh = k.reshape(b, tk, heads, dh).transpose(1, 2).to(p.dtype)
     vh = v.reshape(b, tk, heads, dh).transpose(1, 2).to(p.dtype)
+    if p.flash_sdpa:
+        # "flash" policy: the documented rounding points of an MFMA attention kernel, independent of its tiling:
+        #   S = q.k^T (fp32);  c = fp32(scale*log2 e);  M = ceil(rowmax(S)*c)  - an INTEGER offset in the exp2 domain;
+        #   P = exp2(fma(S, c, -M)) (fp32);  l = sum P (fp32, un-rounded P);  O = (bf16(P) @ V) / l, one rounding to bf16.
+        # Because M is an integer, bf16(exp2(x - M)) = 2^-M * bf16(exp2(x)) exactly: WHICH integer a kernel uses (the
+        # row's final max, or the running max of the key tile it is processing) does not change a single rounded P, so
+        # a tiled online-softmax kernel differs from this formula by fp32 summation order only.
+        c = np.float32(np.float32(1.0 / math.sqrt(dh)) * np.float32(1.4426950408889634))
+        s = (qh @ kh.transpose(-1, -2)).to(torch.float32)
+        M = torch.ceil(s.amax(dim=-1, keepdim=True) * float(c))
+        pw = torch.exp2((s.double() * float(c) - M.double()).to(torch.float32))      # fma: one rounding of the exponent
+        l = pw.sum(dim=-1, keepdim=True)
+        o = (pw.to(torch.bfloat16).to(torch.float32) @ vh.to(torch.float32)) / l
+        return p.r(o.to(p.dtype).transpose(1, 2).reshape(b, tq, d))
     s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
     o = torch.softmax(s, dim=-1) @ vh
     return p.r(o.transpose(1, 2).reshape(b, tq, d))

@@ -3,6 +3,8 @@ one captured graph per variant, replayed in interleaved rounds.
   python scripts/ab_env_step.py LAYERS ROUNDS name:ENV=VAL,ENV=VAL name2:...      (AB_N = tokens per sample, default 1280)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the launch-form switches exist only in the -DLTXK_AB build (csrc/common.h, `make ab`)
+os.environ.setdefault("LTXK_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mlx-video_amd", "libltxk_ab.so"))
 import torch
 from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig, TimestepPlan, precompute_freqs_cis
 from mlx_video_amd.schedulers import create_position_grid
@@ -25,7 +27,8 @@ graphs, outs = {}, {}
 for name, env in variants:
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    model.fuse = int(env.get("LTXK_FUSE", os.environ.get("LTXK_FUSE_DEFAULT", "15")))       # read at construction otherwise
+    model.fuse = int(env.get("LTXK_FUSE", os.environ.get("LTXK_FUSE_DEFAULT", "15")))       # a model attribute, spelled as a variable here
+    model.attn_tail_split = env.get("LTXK_FA_SPLIT", "1") != "0"
     for _ in range(2):
         o = model.forward_tokens(lat, plan, ctx, pe)
     torch.cuda.synchronize()

@@ -22,6 +22,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def ab_lib(dev):
+    """Routes the test's ops calls to the -DLTXK_AB measurement build (libltxk_ab.so), whose launch-form switches are
+    environment variables; the product library reads none (csrc/common.h)."""
+    from mlx_video_amd import _lib
+    with _lib.use_library(_lib.AB_LIB_PATH) as lib:
+        yield lib
+
+
 def _heartbeat():
     """On the GPU box a CPU-oracle comparison can run for minutes without output; a line per minute naming the test
     that is running tells a long comparison from a hang."""

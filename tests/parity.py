@@ -9,7 +9,7 @@
   it stays inside the stated tolerance.
 
 At session end the ledger is written to ``gpurun_out/parity_measured.json`` (scratch on the GPU box; the copy judged is
-``profiles/r02_parity.json``)."""
+``profiles/r03_parity.json``)."""
 import json
 import os
 
@@ -47,9 +47,11 @@ def auto(measured: float, bound: float, tag: str = "") -> float:
     """check() named after the running test (PYTEST_CURRENT_TEST) plus a per-test counter / tag."""
     cur = os.environ.get("PYTEST_CURRENT_TEST", "unknown").split(" ")[0]
     cur = cur.replace("tests/", "").replace(".py::", "::")
+    if tag:                       # tagged checks do not consume a counter slot: adding one never renames the others
+        return check(f"{cur}#{tag}", measured, bound)
     k = _COUNTS.get(cur, 0)
     _COUNTS[cur] = k + 1
-    return check(f"{cur}#{tag or k}", measured, bound)
+    return check(f"{cur}#{k}", measured, bound)
 
 
 def dump() -> None:

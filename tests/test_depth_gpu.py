@@ -49,6 +49,8 @@ def test_forward_depth48_vs_oracle(dev):
     ref, hidden = O.ltx_forward(tok.float(), ts.float(), cp.float(), pe, W, cfg, O.BF16, return_hidden=True)
     ref32 = O.ltx_forward(tok.float(), ts.float(), cp.float(), pe, W, cfg, O.F32)
     parity.check("dit.depth48_forward.velocity_vs_bf16_oracle", rel_l2(v.float(), ref), 2e-2)
+    reff = O.ltx_forward(tok.float(), ts.float(), cp.float(), pe, W, cfg, O.BF16_FLASH)
+    parity.check("dit.depth48_forward.velocity_vs_bf16_oracle_flash_policy", rel_l2(v.float(), reff), 2e-2)
     # context: how far the bf16 policy itself sits from pure fp32 at this depth (the reference's own storage error)
     parity.LEDGER["dit.depth48_forward.bf16_oracle_vs_fp32_oracle"] = {"measured": rel_l2(ref, ref32), "bound": None,
                                                                      "note": "not a product error: bf16-policy oracle vs fp32 oracle"}
@@ -69,6 +71,10 @@ def test_dev_loop_40_steps_depth48_vs_oracle(dev):
     assert torch.equal(out, eager)                                   # 40 graph replays == 40 eager steps, bit for bit
     ref = O.denoise_dev(lat.float(), pos.numpy(), cp.float(), cn.float(), W, cfg, sig.tolist(), O.BF16, 4.0, compiled=True)
     parity.check("loop.dev_40step_cfg4_depth48.final_latents_vs_bf16_oracle", rel_l2(out.float(), ref), 4e-2)
+    reff = O.denoise_dev(lat.float(), pos.numpy(), cp.float(), cn.float(), W, cfg, sig.tolist(), O.BF16_FLASH, 4.0, compiled=True)
+    parity.check("loop.dev_40step_cfg4_depth48.final_latents_vs_bf16_oracle_flash_policy", rel_l2(out.float(), reff), 4e-2)
+    parity.LEDGER["loop.dev_40step_cfg4_depth48.bf16_oracle_fp32P_vs_flash_policy"] = {
+        "measured": rel_l2(ref, reff), "bound": None, "note": "not a product error: the two oracle attention policies against each other"}
     # ... and the 3-step prefix, for the per-step growth of the error
     o3 = denoise_dev(lat.to(dev), pos.to(dev), cp.to(dev), cn.to(dev), model, sig[:4], **kw)
     r3 = O.denoise_dev(lat.float(), pos.numpy(), cp.float(), cn.float(), W, cfg, sig[:4].tolist(), O.BF16, 4.0, compiled=True)

@@ -1,0 +1,86 @@
+"""Full WIDTH and DEPTH together: the default launch structure - row statistics
+carried FF2 -> next block's norm, raw q normalised + rotated inside flash_attn, q|k on the 320x256 tile, (1+scale) folded
+into ada_combine - inside a multi-layer comparison at the bench shape (D=4096, 32 heads, FF 16384, N=1280 tokens, S=1024,
+B=2 CFG pair), with the per-layer hidden error against the oracle under BOTH attention policies:
+
+  * ``O.BF16``        P stays fp32 until after P.V (MLX's documented "fp32 inside, one rounding");
+  * ``O.BF16_FLASH``  P rounded to bf16 where the kernel rounds it (oracle/dit.py::sdpa) - what is left against this one is
+                      fp32 summation order and the bf16 rounding flips it causes downstream.
+
+Plus: the same model with every launch-structure fusion off (fuse=0) agrees with the default (fuse=15) to <= 1 bf16 ulp
+on >= 99.8 % of the residual stream after every layer; and the full-size 33x512x512 VAE decode (the real 5 res blocks per
+stage) against the oracle."""
+import pytest
+import torch
+
+import parity
+from oracle import dit as O
+from parity import rel_l2
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+L = 4
+
+
+def _ulp_far_frac(a, b, ulps=1):
+    """fraction of elements more than `ulps` bf16 ulps apart (ulp taken at max(|a|,|b|))."""
+    a, b = a.float().cpu(), b.float().cpu()
+    tol = ulps * (2.0 ** -7) * torch.maximum(a.abs(), b.abs()).clamp_min(1e-6)
+    return float(((a - b).abs() > tol).float().mean())
+
+
+def test_forward_fullwidth_4_layers_vs_oracle_per_layer(dev):
+    from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig, TimestepPlan, precompute_freqs_cis
+    cfg = O.DiTConfig(num_layers=L)
+    W = O.make_weights(cfg, seed=31)
+    Wd = {k: v.to(dev) for k, v in W.items()}
+    model = LTXModel(LTXModelConfig(num_layers=L), Wd)                      # default launch structure (fuse=15)
+    plain = LTXModel(LTXModelConfig(num_layers=L), Wd, fuse=0)              # every fusion off
+    B, F, Hh, Ww, S = 2, 5, 16, 16, 1024
+    N = F * Hh * Ww
+    g = torch.Generator().manual_seed(45)
+    lat = torch.randn(1, N, 128, generator=g).to(BF).expand(B, N, 128).contiguous()
+    ctx = torch.randn(B, S, 3840, generator=g).to(BF)
+    ts = torch.full((B, N), 0.909375).to(BF)
+    pos = torch.from_numpy(O.create_position_grid(1, F, Hh, Ww))
+    pe = O.precompute_freqs_cis(pos, cfg.dim)
+    pe_d = precompute_freqs_cis(pos.to(dev), cfg.dim)
+    plan = TimestepPlan.from_timesteps(ts.to(dev))
+    hid, hid0 = [], []
+    v = model.forward_tokens(lat.to(dev), plan, ctx.to(dev), pe_d, hidden=hid)
+    v0 = plain.forward_tokens(lat.to(dev), plan, ctx.to(dev), pe_d, hidden=hid0)
+    torch.cuda.synchronize()
+    assert len(hid) == L and v.shape == (B, N, 128)
+    # ---- launch structure: fuse=15 vs fuse=0, layer by layer ----
+    for i in range(L):
+        far = _ulp_far_frac(hid[i], hid0[i], 1)
+        parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.layer{i}.frac_beyond_1ulp", far, 2e-3)
+    parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.velocity_rel_l2", rel_l2(v, v0), 5e-3)
+    # ---- against the oracle, both attention policies, per layer ----
+    for name, pol, tol_h, tol_v in (("fp32P", O.BF16, 1e-2, 1e-2), ("flash", O.BF16_FLASH, 5e-3, 5e-3)):
+        ref, rh = O.ltx_forward(lat.float(), ts.float(), ctx.float(), pe, W, cfg, pol, return_hidden=True)
+        for i in range(L):
+            parity.check(f"dit.fullwidth_L{L}.hidden{i}_vs_bf16_oracle_{name}", rel_l2(hid[i].float().cpu(), rh[i]), tol_h)
+        parity.check(f"dit.fullwidth_L{L}.velocity_vs_bf16_oracle_{name}", rel_l2(v.float().cpu(), ref), tol_v)
+    assert not torch.equal(v[0], v[1])
+
+
+def test_vae_decode_fullsize_vs_oracle(dev):
+    """33x512x512 (latent 5x16x16), the decoder's real depth (5 res blocks per stage), same weights: decoder.py:361-450."""
+    from oracle import vae as OV
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, to_uint8_frames
+    Wv = OV.make_decoder_weights(seed=9, layers_per_block=5)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in Wv.items()}, num_layers_per_block=5)
+    g = torch.Generator().manual_seed(10)
+    zl = torch.randn(1, 128, 5, 16, 16, generator=g).to(BF)
+    vid = dec(zl.to(dev))
+    u8 = to_uint8_frames(vid)
+    torch.cuda.synchronize()
+    ref = OV.vae_decode(zl.float(), Wv, O.BF16, layers_per_block=5)
+    assert vid.shape == ref.shape == (1, 3, 33, 512, 512)
+    parity.check("vae.decode_fullsize_33x512x512_5blocks.rel_l2_vs_bf16_oracle", rel_l2(vid.float().cpu(), ref), 2e-2)
+    # generate.py:3894-3898 on the oracle's frames
+    ru8 = ((ref.to(BF).float() + 1) / 2).clamp(0, 1).to(BF).float().mul(255).to(BF).to(torch.uint8)[0].permute(1, 2, 3, 0)
+    d = (u8[0].cpu().int() - ru8.int()).abs().float()
+    parity.check("vae.decode_fullsize_33x512x512_5blocks.uint8_mean_abs_diff", float(d.mean()), 1.0)
+    parity.check("vae.decode_fullsize_33x512x512_5blocks.uint8_p99_abs_diff", float(torch.quantile(d.flatten()[::97], 0.99)), 4.0)

@@ -66,9 +66,9 @@ BIG_SHAPES = [(320, 256, 64), (2560, 1024, 256), (700, 512, 192), (2560, 4096, 1
 
 
 @pytest.mark.parametrize("M,N,K", BIG_SHAPES)
-def test_gemm_320x256_tile_equals_160x256_tile(dev, M, N, K, monkeypatch):
+def test_gemm_320x256_tile_equals_160x256_tile(dev, M, N, K, monkeypatch, ab_lib):
     """The 320x256-tile kernel (gemm.hip, taken for FF1-sized launches) walks K in the same order with the same MFMA as
-    the 160x256 one: forced on (LTXK_GEMM_BIG=2) it must give the same bits, for every epilogue it supports, with and
+    the 160x256 one: forced on (LTXK_GEMM_BIG=2 in the A/B build of the library) it must give the same bits, for every epilogue it supports, with and
     without bias, with a ragged last row tile (M=700, 1296), a strided A (lda = K + 64) and when its output is a strided view."""
     from mlx_video_amd import ops
     g = torch.Generator(device=dev).manual_seed(M * 3 + N + K)
@@ -100,16 +100,17 @@ def test_gemm_ff1_takes_the_320x256_tile(dev, monkeypatch):
     a = torch.randn((2560, 4096), generator=g, device=dev).to(BF)
     w = (torch.randn((16384, 4096), generator=g, device=dev) * 0.02).to(BF)
     b = (torch.randn(16384, generator=g, device=dev) * 0.1).to(BF)
-    monkeypatch.delenv("LTXK_GEMM_BIG", raising=False)
-    y1 = ops.gemm(a, w, b, epilogue=1)
+    from mlx_video_amd import _lib
+    y1 = ops.gemm(a, w, b, epilogue=1)                       # the product library
     monkeypatch.setenv("LTXK_GEMM_BIG", "0")
-    y0 = ops.gemm(a, w, b, epilogue=1)
+    with _lib.use_library(_lib.AB_LIB_PATH):                 # the A/B build with the 320x256 tile switched off
+        y0 = ops.gemm(a, w, b, epilogue=1)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
 
 
 @pytest.mark.parametrize("M,N,K", [(2560, 1024, 256), (700, 512, 192), (2048, 768, 320)])
-def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monkeypatch):
+def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monkeypatch, ab_lib):
     """Row statistics, the transposed (V^T) output - vector stores at T % 4 == 0, element stores at T = 350 - and the
     split k | V^T output of the 320x256-tile kernel against the 160x256 one: same bits."""
     from mlx_video_amd import ops
@@ -141,3 +142,24 @@ def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monk
     assert torch.equal(k2, y[:, :256]) and torch.equal(v2[:, :, :T], vt[:, 256:, :T])
     ref = (y.float() ** 2).reshape(M, N // 64, 64).sum(-1)
     assert float((ss[:, :-1] - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 128), (160, 448, 64), (2560, 576, 256), (33, 64, 64)])
+def test_gemm_sumsq_when_N_is_not_a_multiple_of_256(dev, M, N, K):
+    """Row statistics with a ragged last column tile (N % 256 != 0; the C ABI only asks for N % 64 == 0): the waves of that
+    tile whose 64-column block lies past N must not store a partial - the slot is the NEXT row's first partial (a race
+    with its real writer) or, on the last row, past the buffer.  Canary-padded buffer with sumsq_ld == N/64 exactly."""
+    from mlx_video_amd import ops
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g, device=dev).to(BF)
+    w = (torch.randn((N, K), generator=g, device=dev) * 0.05).to(BF)
+    b = (torch.randn(N, generator=g, device=dev) * 0.1).to(BF)
+    P = N // 64
+    for _ in range(3):
+        buf = torch.full((M * P + 64,), -7.0, device=dev, dtype=torch.float32)
+        ss = buf[:M * P].view(M, P)
+        y = ops.gemm(a, w, b, sumsq=ss)
+        torch.cuda.synchronize()
+        assert torch.all(buf[M * P:] == -7.0), "sumsq written past the buffer"
+        ref = (y.float() ** 2).reshape(M, P, 64).sum(-1)
+        assert float((ss - ref).abs().max() / ref.abs().max()) < 1e-5

@@ -311,3 +311,42 @@ int main() {
     subprocess.run(["g++", "-O1", "-o", str(tmp_path / "m"), str(tmp_path / "m.cpp")], check=True)
     out = subprocess.run([str(tmp_path / "m")], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "OK", out.stdout
+
+
+def test_vae_statistics_keys_match_exactly(tmp_path):
+    """A real PyTorch LTX-2 checkpoint carries five per-channel statistics tensors plus the audio VAE's pair of the same
+    shape (reference convert.py:277-286 skips the extras; decoder.py:667-690 / encoder.py:141-157 read only
+    vae.per_channel_statistics.{mean-of-means,std-of-means} and the plain mean/std names).  In adversarial file order
+    (the impostors LAST, so a last-key-wins map would take them) mean and std must still be the right tensors."""
+    import collections
+    from mlx_video_amd import weights
+    f = lambda v: torch.full((128,), float(v))
+    raw = collections.OrderedDict()
+    raw["vae.per_channel_statistics.mean-of-means"] = f(1)
+    raw["vae.per_channel_statistics.std-of-means"] = f(2)
+    raw["vae.per_channel_statistics.channel"] = f(30)
+    raw["vae.per_channel_statistics.mean-of-stds"] = f(40)
+    raw["vae.per_channel_statistics.mean-of-stds_over_std-of-means"] = f(50)
+    raw["audio_vae.per_channel_statistics.mean-of-means"] = f(60)
+    raw["audio_vae.per_channel_statistics.std-of-means"] = f(70)
+    raw["vae.decoder.conv_in.conv.bias"] = torch.zeros(4)
+    raw["vae.encoder.conv_in.conv.bias"] = torch.zeros(4)
+    dw = weights.vae_decoder_weights(raw, "cpu")
+    ew = weights.vae_encoder_weights(raw, "cpu")
+    assert float(dw["latents_mean"][0]) == 1.0 and float(dw["latents_std"][0]) == 2.0
+    assert float(ew["per_channel_statistics.mean"][0]) == 1.0 and float(ew["per_channel_statistics.std"][0]) == 2.0
+    assert not any("audio" in k or "of-stds" in k or k.endswith("channel") for k in list(dw) + list(ew))
+    for k in ("vae.per_channel_statistics.channel", "vae.per_channel_statistics.mean-of-stds", "audio_vae.per_channel_statistics.mean-of-means",
+              "audio_vae.per_channel_statistics.std-of-means", "vae.per_channel_statistics.mean-of-stds_over_std-of-means"):
+        assert weights._vae_encoder_key(k) is None and weights._vae_decoder_key(k) is None, k
+    # plain names override *-of-means in either file order (decoder.py:676-689, encoder.py:152-157) ...
+    for order in (("per_channel_statistics.mean", "vae.per_channel_statistics.mean-of-means"),
+                  ("vae.per_channel_statistics.mean-of-means", "per_channel_statistics.mean")):
+        r2 = collections.OrderedDict((k, f(9 if k == "per_channel_statistics.mean" else 1)) for k in order)
+        r2["vae.per_channel_statistics.std-of-means"] = f(2)
+        assert float(weights.vae_decoder_weights(r2, "cpu")["latents_mean"][0]) == 9.0
+        assert float(weights.vae_encoder_weights(r2, "cpu")["per_channel_statistics.mean"][0]) == 9.0
+    # ... and an explicit latents_mean overrides both (decoder.py:690-695)
+    r3 = collections.OrderedDict([("latents_mean", f(5)), ("per_channel_statistics.mean", f(9)), ("latents_std", f(6))])
+    d3 = weights.vae_decoder_weights(r3, "cpu")
+    assert float(d3["latents_mean"][0]) == 5.0 and float(d3["latents_std"][0]) == 6.0

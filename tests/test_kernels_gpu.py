@@ -128,6 +128,16 @@ def test_flash_attn(dev, B, H, Tq, Tk):
     torch.cuda.synchronize()
     # P is rounded to bf16 before P.V (flash form); the oracle keeps P in fp32: stated tolerance 1e-2 rel-L2
     parity.auto(rel_l2(out.reshape(B, Tq, D), ref), 1e-2)
+    # ... and against the oracle's "flash" policy, which rounds P where the kernel does (integer exp2-domain offset, so
+    # the rounded P does not depend on the tiling): what is left is fp32 summation order + final bf16 rounding flips
+    ref_f = O.sdpa(q.float(), k.float(), v.float(), H, O.BF16_FLASH)
+    parity.auto(rel_l2(out.reshape(B, Tq, D), ref_f), 5e-4, tag="vs_flash_policy")
+    # batch-invariant launch form (LTXK_ATTN_NO_TAIL_SPLIT): the same rounding points, another summation order
+    out2 = torch.empty_like(out)
+    ops.flash_attn(q.reshape(B * Tq, D).to(dev), k.reshape(B * Tk, D).to(dev), vt.to(dev), out2, B, H, Tq, Tk,
+                   1.0 / math.sqrt(128), tail_split=False)
+    torch.cuda.synchronize()
+    parity.auto(rel_l2(out2.reshape(B, Tq, D), ref_f), 5e-4, tag="no_tail_split_vs_flash_policy")
 
 
 def test_flash_attn_spiked_max(dev):
@@ -145,6 +155,8 @@ def test_flash_attn_spiked_max(dev):
     ops.flash_attn(q.reshape(-1, D).to(dev), k.reshape(-1, D).to(dev), vt.to(dev), out, B, H, Tq, Tk, 1.0 / math.sqrt(128))
     torch.cuda.synchronize()
     parity.auto(rel_l2(out.reshape(B, Tq, D), ref), 1e-2)
+    # the rescale multiplies O and l by an exact power of two (integer offsets): still only summation order vs the flash policy
+    parity.auto(rel_l2(out.reshape(B, Tq, D), O.sdpa(q.float(), k.float(), v.float(), H, O.BF16_FLASH)), 5e-4, tag="vs_flash_policy")
 
 
 @pytest.mark.parametrize("mod", [False, True])

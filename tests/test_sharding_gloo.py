@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 (and 4) gloo process groups exercise CfgPairSharding's partition and
+"""N>1 path on CPU: world_size-2, -4 and -8 gloo process groups exercise CfgPairSharding's partition and
 velocity exchange with stand-in forward/tail functions (the HIP kernels need a GPU; what is checked here
 is that the sharded loop reproduces the single-process loop bit for bit and stays replicated)."""
 import os
@@ -66,7 +66,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])          # 8 = config 4's actual layout: 4 seeds x CFG pair
 def test_cfg_pair_sharding_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -90,3 +90,16 @@ def test_cfg_pair_sharding_rejects_odd_world():
     from mlx_video_amd.sharding import CfgPairSharding
     with pytest.raises(ValueError, match="even world size"):
         CfgPairSharding(None, 0, 3)
+
+
+def test_bench_gpus_n_without_launcher_never_reports_one_gpu():
+    """`python bench.py --gpus 8` with no RANK in the environment starts its own ranks or fails; on a machine with fewer
+    GPUs (this container has none) it must exit non-zero WITHOUT printing a result line."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LTXK_BENCH_REHEARSAL")}
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 GPUs visible: the launcher would really start the bench")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in r.stderr

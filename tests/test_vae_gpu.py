@@ -308,10 +308,10 @@ def test_on_frames_ready_covers_89_frames(dev):
 
 @pytest.mark.parametrize("cout,shape", [(128, (3, 160, 160)), (256, (3, 128, 128)), (512, (2, 112, 112))])
 @pytest.mark.parametrize("res", [False, True])
-def test_conv3d_short_last_round_as_half_tiles(dev, res, cout, shape, monkeypatch):
+def test_conv3d_short_last_round_as_half_tiles(dev, res, cout, shape, monkeypatch, ab_lib):
     """Convs whose tile count ends in a short round of 256 CUs - 128 channels on 3x160x160 voxels = 300 tiles of 256 rows,
     256 channels on 3x128x128 = 308 tiles of 160 rows, 512 channels on 2x112x112 = 157 x 2 tiles: the rows past the last
-    whole round run as a second launch of lower tiles (conv3d.hip, LTXK_CONV_TAIL).  Every output row is still one K-ordered
+    whole round run as a second launch of lower tiles (conv3d.hip; LTXK_CONV_TAIL=0 in the A/B build switches it off).  Every output row is still one K-ordered
     sum: same bits as the single launch, with and without the residual."""
     from mlx_video_amd import video_vae as V
     g = torch.Generator(device=dev).manual_seed(3 + cout)
