@@ -233,25 +233,31 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, heads: int, p: Prec) -> Tensor:
 
 def attention(x: Tensor, W: Dict[str, Tensor], prefix: str, heads: int, p: Prec,
               context: Optional[Tensor] = None, pe: Optional[Tuple[Tensor, Tensor]] = None,
-              eps: float = 1e-6) -> Tensor:
-    """attention.py:102-142."""
+              eps: float = 1e-6, taps: Optional[dict] = None, tag: str = "") -> Tensor:
+    """attention.py:102-142.  ``taps``: receives every intermediate (test instrumentation)."""
     ctx = x if context is None else context
     q = linear(x, W[f"{prefix}.to_q.weight"], W[f"{prefix}.to_q.bias"], p)
     k = linear(ctx, W[f"{prefix}.to_k.weight"], W[f"{prefix}.to_k.bias"], p)
     v = linear(ctx, W[f"{prefix}.to_v.weight"], W[f"{prefix}.to_v.bias"], p)
+    if taps is not None:
+        taps[f"{tag}q_raw"], taps[f"{tag}k_raw"], taps[f"{tag}v"] = q, k, v
     q = rms_norm(q, p, eps, W[f"{prefix}.q_norm.weight"])    # over the full inner dim
     k = rms_norm(k, p, eps, W[f"{prefix}.k_norm.weight"])
     if pe is not None:
         q = apply_split_rotary_emb(q, pe[0], pe[1], p)
         k = apply_split_rotary_emb(k, pe[0], pe[1], p)
     o = sdpa(q, k, v, heads, p)
+    if taps is not None:
+        taps[f"{tag}q"], taps[f"{tag}k"], taps[f"{tag}att"] = q, k, o
     return linear(o, W[f"{prefix}.to_out.weight"], W[f"{prefix}.to_out.bias"], p)
 
 
-def feed_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, p: Prec) -> Tensor:
+def feed_forward(x: Tensor, W: Dict[str, Tensor], prefix: str, p: Prec, taps: Optional[dict] = None) -> Tensor:
     """feed_forward.py:35-40."""
     h = linear(x, W[f"{prefix}.proj_in.weight"], W[f"{prefix}.proj_in.bias"], p)
     h = gelu_tanh(h, p)
+    if taps is not None:
+        taps["hff"] = h
     return linear(h, W[f"{prefix}.proj_out.weight"], W[f"{prefix}.proj_out.bias"], p)
 
 
@@ -269,18 +275,26 @@ def modulate(x: Tensor, scale: Tensor, shift: Tensor, p: Prec) -> Tensor:
 
 
 def transformer_block(x: Tensor, ts: Tensor, context: Tensor, pe, W: Dict[str, Tensor], i: int,
-                      cfg: DiTConfig, p: Prec) -> Tensor:
-    """transformer.py:247-261,342-347 (video branch only)."""
+                      cfg: DiTConfig, p: Prec, taps: Optional[dict] = None) -> Tensor:
+    """transformer.py:247-261,342-347 (video branch only).  ``taps``: receives every intermediate."""
     pre = f"transformer_blocks.{i}"
     table = W[f"{pre}.scale_shift_table"]
     shift_msa, scale_msa, gate_msa = ada_values(table, ts, 0, 3, p)
     nx = modulate(rms_norm(x, p, cfg.norm_eps), scale_msa, shift_msa, p)
-    x = p.r(x + p.r(attention(nx, W, f"{pre}.attn1", cfg.heads, p, pe=pe, eps=cfg.norm_eps) * gate_msa))
-    x = p.r(x + attention(rms_norm(x, p, cfg.norm_eps), W, f"{pre}.attn2", cfg.heads, p,
-                          context=context, eps=cfg.norm_eps))
+    if taps is not None:
+        taps["x0"], taps["nx1"] = x, nx
+    x = p.r(x + p.r(attention(nx, W, f"{pre}.attn1", cfg.heads, p, pe=pe, eps=cfg.norm_eps, taps=taps, tag="a1.") * gate_msa))
+    nx = rms_norm(x, p, cfg.norm_eps)
+    if taps is not None:
+        taps["x1"], taps["nx2"] = x, nx
+    x = p.r(x + attention(nx, W, f"{pre}.attn2", cfg.heads, p, context=context, eps=cfg.norm_eps, taps=taps, tag="a2."))
     shift_mlp, scale_mlp, gate_mlp = ada_values(table, ts, 3, 6, p)
     nx = modulate(rms_norm(x, p, cfg.norm_eps), scale_mlp, shift_mlp, p)
-    x = p.r(x + p.r(feed_forward(nx, W, f"{pre}.ff", p) * gate_mlp))
+    if taps is not None:
+        taps["x2"], taps["nx3"] = x, nx
+    x = p.r(x + p.r(feed_forward(nx, W, f"{pre}.ff", p, taps=taps) * gate_mlp))
+    if taps is not None:
+        taps["x3"] = x
     return x
 
 

