@@ -312,6 +312,14 @@ int ltxk_patchify_cl(const void* video, void* out, int32_t B, int32_t C, int32_t
 int ltxk_to_uint8(const void* x, void* out, int32_t B, int32_t C, int32_t F, int32_t H, int32_t W,
                   void* stream);
 
+/* Area resize of conditioning frames, DOWNscaling only: cv2.resize(frame, (OW,OH), interpolation=cv2.INTER_AREA) on float
+ * frames (prepare_video_for_encoding, utils.py:699-705; OpenCV resizeArea_: destination pixel d averages the source
+ * interval [d*scale,(d+1)*scale) with fractional end weights, horizontal pass then vertical pass in fp32).
+ * x: `planes` contiguous (H,W) planes, fp32 (x_is_f32 != 0) or bf16; out: planes x (OH,OW) bf16.  Linear, so it may be
+ * applied to frames already mapped to [-1,1].                                               */
+int ltxk_resize_area(const void* x, int32_t x_is_f32, void* out, int64_t planes, int32_t H, int32_t W,
+                     int32_t OH, int32_t OW, void* stream);
+
 /* GroupNorm over (D*H*W, C/G) per (batch, group) in fp32 + affine [+ residual] [+ SiLU]:
  * upsampler.py:65-98,160-174.  x,out (B,V,C) bf16 channels-last, gamma/beta (C) bf16.
  *   y = bf16((x-mean)/sqrt(var+eps)*gamma+beta); if resid: y = bf16(y+resid); if silu: bf16(silu(y)) */

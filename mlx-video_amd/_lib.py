@@ -87,6 +87,7 @@ SIGNATURES = {
     "ltxk_patchify_cl": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                    c_void_p]),
     "ltxk_to_uint8": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "ltxk_resize_area": (c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "ltxk_groupnorm_act": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                      c_float, c_int32, c_void_p]),
     "ltxk_tile_blend_accum": (c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p] * 5 + [c_int32] * 8 + [c_void_p]),

@@ -27,6 +27,7 @@ constexpr int FA_K_BYTES = FA_BK * FA_DH * 2;    // 16 KiB: [64 keys][256 B]
 constexpr int FA_V_BYTES = FA_DH * FA_BK * 2;    // 16 KiB: [128 d][128 B]
 constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES;
 constexpr int FA_LDS = 2 * FA_STAGE;
+constexpr int FA_DEFAULT_MFMA = 32;   // MFMA shape of the shipped kernel: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (fa_body16)
 
 struct FaParams {
   const bf16* q; const bf16* k; const bf16* vt; bf16* out;
@@ -56,7 +57,7 @@ __device__ __forceinline__ void fa_prep_q(const FaParams& p, bf16x8 (&qf)[8], in
     const f32x4 v = *(const f32x4*)(sp + i);
     ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
   }
-  ss += __shfl_xor(ss, 32, 64);
+  ss = lane_xor32_sum(ss);
   const float rstd = rsqrtf(ss / (float)(p.H * FA_DH) + p.eps);
   const bf16* wp = p.q_w + h * FA_DH + hh * 8;
   const size_t cso = ((size_t)h * p.Tq + qrow) * 64 + hh * 8;
@@ -283,7 +284,7 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
     for (int kbi = 0; kbi < NKB; ++kbi)
 #pragma unroll
       for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kbi][j]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = lane_xor32_max(mx);
     // Deferred rescale: the running max is only raised (and O, l rescaled: 65 VALU ops per lane) when some
     // row's max grew by more than 2^FA_DEFER in the exponent domain; otherwise P is taken against the old
     // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
@@ -334,7 +335,7 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot = lane_xor32_sum(l_run);
   if (KS == 2) {
     // ---- merge the key halves of each wave pair through LDS (the K/V ring is dead now) ----
     __syncthreads();
@@ -409,7 +410,348 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_attn_kernel(FaParams p) {
   }
 }
 
+// =====================================================================================================================
+// The same kernel on v_mfma_f32_16x16x32_bf16 (round 3).  MI355X_MICROARCH.md (DVFS give-back, item 7) and
+// profiles/r02_mfma_power_probe.log price the 16x16x32 shape 12-15 % cheaper in held clock than 32x32x16 on random data at
+// equal cycles per FLOP.  Geometry per wave is unchanged (32 query rows x 64-key tiles, 4 waves, 2 workgroups per CU);
+// what changes is the operand map.  With g = lane >> 4, c = lane & 15:
+//   S^T block (kb = 16-key block 0..3, qb = 16-query block 0..1) = K(kb) . Q^T(qb), 4 k-steps of 32 channels:
+//     A = K fragment: lane (c,g) holds key row keymap(kb, c), channels 32ks + 8g .. +7          (one ds_read_b128)
+//     B = Q fragment: lane (c,g) holds query 16qb + c, the same channels                            (registers, whole kernel)
+//     D: lane (c,g) register j = S^T[row 4g + j of block kb][query 16qb + c]
+//   The softmax axis (keys) is registers x the four lane groups g: row max / sum = lane-local + two exchanges (lane ^ 16,
+//   lane ^ 32: v_permlane16_swap / v_permlane32_swap, one VALU instruction each - no LDS round trip).
+//   O^T block (db = 16-channel block 0..7, qb) += V^T(db, kc) . P^T(kc, qb) over the two 32-key chunks kc of the tile:
+//     B = P^T: lane (c,g) k-slots 8g .. 8g+7 = its own registers { S[2kc][qb][0..3], S[2kc+1][qb][0..3] } exponentiated
+//     A = V^T fragment: lane (c,g) holds channel 16db + c, k-slots 8g .. 8g+7
+//   keymap(kb, r) = 32 (kb >> 1) + 8 (r >> 2) + 4 (kb & 1) + (r & 3) makes those eight k-slots the eight CONTIGUOUS keys
+//   32 kc + 8g + 0..7, so the V^T fragment is one conflict-free ds_read_b128 and P never touches LDS (as in the 32x32 form).
+// LDS images: V^T as before; K rows are swizzled by kswz(row) = 4 ((row >> 3) & 3) + (row & 3) - the S^T row index c the
+// lane reads it for - instead of row & 15: the 16 lanes of a ds_read_b128 group are {c in 0-3,12-15 of one g} + {c in 4-11
+// of g ^ 1}, both sets closed under c ^ 1, so chunk ^ c is a bijection onto the 16 chunk positions.
+// =====================================================================================================================
+__device__ __forceinline__ constexpr int fa16_keymap(int kb, int r) { return 32 * (kb >> 1) + 8 * (r >> 2) + 4 * (kb & 1) + (r & 3); }
+__device__ __forceinline__ int fa16_kswz(int row) { return 4 * ((row >> 3) & 3) + (row & 3); }
 
+// RMSNorm * weight (+ SPLIT RoPE) of the wave's Q fragments in the 16x16x32 operand map: fragment (qb, ks) of lane (c,g)
+// holds channels 32ks + 8g + j; the rotation partner 64 channels up is fragment ks + 2 of the same lane.  Same op order
+// and rounding points as fa_prep_q / qknorm_rope_kernel.
+__device__ __forceinline__ void fa16_prep_q(const FaParams& p, bf16x8 (&qf)[2][4], int b, int h, int q0, int c, int g) {
+  const int half = p.q_ss_n >> 1;
+  const bf16* wp = p.q_w + h * FA_DH + g * 8;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    int qrow = q0 + 16 * qb + c;
+    qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+    const float* sp = p.q_ss + (size_t)(b * p.Tq + qrow) * p.q_ss_ld + (g & 1) * half;
+    float ss = 0.f;
+    for (int i = 0; i < half; i += 4) {
+      const f32x4 v = *(const f32x4*)(sp + i);
+      ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
+    }
+    ss = lane_xor16_sum(ss);                      // half 0 + half 1 (lanes g and g ^ 1 hold one each): same sum as fa_prep_q
+    const float rstd = rsqrtf(ss / (float)(p.H * FA_DH) + p.eps);
+    const size_t cso = ((size_t)h * p.Tq + qrow) * 64 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 wa = *(const bf16x8*)(wp + ks * 32), wb = *(const bf16x8*)(wp + 64 + ks * 32);
+      f32x4 c0, c1, s0, s1;
+      if (p.cosb) {
+        c0 = *(const f32x4*)(p.cosb + cso + ks * 32); c1 = *(const f32x4*)(p.cosb + cso + ks * 32 + 4);
+        s0 = *(const f32x4*)(p.sinb + cso + ks * 32); s1 = *(const f32x4*)(p.sinb + cso + ks * 32 + 4);
+      }
+      bf16x8 oa, ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x1 = rbf((float)qf[qb][ks][j] * rstd * (float)wa[j]);
+        const float x2 = rbf((float)qf[qb][ks + 2][j] * rstd * (float)wb[j]);
+        if (p.cosb) {
+          const float cc = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
+          oa[j] = (bf16)(x1 * cc - sn * x2);
+          ob[j] = (bf16)(x2 * cc + sn * x1);
+        } else {
+          oa[j] = (bf16)x1;
+          ob[j] = (bf16)x2;
+        }
+      }
+      qf[qb][ks] = oa;
+      qf[qb][ks + 2] = ob;
+    }
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh, int q0, int kh, int wave, int lane) {
+  constexpr int NW = 4;
+  constexpr int NKC = 2 / KS;                    // 32-key chunks of a tile this wave works on
+  const int c = lane & 15, g = lane >> 4;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  // ---- Q: the wave's 32 x 256-byte block by LDS-DMA into its private corner of ring slot 1 (rows swizzled by row & 15) ----
+  bf16x8 qf[2][4];
+  {
+    char* qreg = smem + FA_STAGE + wave * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = 4 * j + (lane >> 4);
+      int qrow = q0 + row;
+      qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+      glds16(p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + (((lane & 15) ^ (row & 15)) << 3), qreg + j * 1024);
+    }
+  }
+  // ---- loader addressing: K piece = 4 key rows x 256 B (chunk position = chunk ^ kswz(row)); V^T piece = 8 d-rows x 128 B ----
+  const int k_lrow = lane >> 4, k_slot = lane & 15;
+  const int v_lrow = lane >> 3, v_slot = lane & 7;
+  const bf16* kbase = p.k + (size_t)b * p.Tk * p.ldk + h * FA_DH;
+  const bf16* vbase = p.vt + (size_t)bh * FA_DH * p.ldvt;
+  unsigned koff[4], voff[4];
+  const int last_ragged = (p.Tk & (FA_BK - 1)) != 0 ? (p.Tk - 1) / FA_BK : -1;
+  auto set_koff = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + i * NW) * 4 + k_lrow;
+      int key = row;
+      if (t == last_ragged) key = (t * FA_BK + row < p.Tk ? t * FA_BK + row : p.Tk - 1) - t * FA_BK;
+      koff[i] = (unsigned)key * (unsigned)p.ldk * 2u + ((unsigned)(k_slot ^ fa16_kswz(row)) << 4);
+    }
+  };
+  set_koff(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = (wave + i * NW) * 8 + v_lrow;
+    voff[i] = (unsigned)d * (unsigned)p.ldvt * 2u + ((unsigned)(v_slot ^ ((d >> 1) & 7)) << 4);
+  }
+  const uint64_t kstep = (uint64_t)FA_BK * p.ldk * 2, vstep = FA_BK * 2;
+  auto issue_k = [&](int i, int t, int st) __attribute__((always_inline)) {
+    glds16_s((uint64_t)(uintptr_t)kbase + (uint64_t)t * kstep, koff[i], smem + st * FA_STAGE + (wave + i * NW) * 1024);
+  };
+  auto issue_v = [&](int i, int t, int st) __attribute__((always_inline)) {
+    glds16_s((uint64_t)(uintptr_t)vbase + (uint64_t)t * vstep, voff[i], smem + st * FA_STAGE + FA_K_BYTES + (wave + i * NW) * 1024);
+  };
+
+  f32x4 o[8][2];
+#pragma unroll
+  for (int db = 0; db < 8; ++db)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[db][qb][j] = 0.f;
+  float mc_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};     // per query block qb (query row 16qb + c)
+
+  const int nt = (p.Tk + FA_BK - 1) / FA_BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { issue_k(i, 0, 0); issue_v(i, 0, 0); }
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the 8 Q pieces have landed
+  {
+    const char* qreg = smem + FA_STAGE + wave * 8192;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = 16 * qb + c;
+        qf[qb][ks] = *(const bf16x8*)(qreg + row * 256 + (((4 * ks + g) ^ (row & 15)) << 4));
+      }
+  }
+  if (p.q_ss) fa16_prep_q(p, qf, b, h, q0, c, g);
+
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool pre = t + 1 < nt;
+    const int tn = pre ? t + 1 : t, stn = (t + 1) & 1;
+    if (tn == last_ragged && pre) set_koff(tn);
+    const char* sk = smem + (t & 1) * FA_STAGE;
+    const char* sv = sk + FA_K_BYTES;
+
+    // ---- S^T = K . Q^T: one group of 8 MFMAs per 16-key block (4 K fragments x 2 query blocks); the next block's
+    // fragments are requested before this block's MFMAs issue; one K and one V^T piece of the next tile per group ----
+    f32x4 s[2 * NKC][2];
+#pragma unroll
+    for (int i = 0; i < 2 * NKC; ++i)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[i][qb][j] = 0.f;
+    {
+      constexpr int NG = 2 * NKC;
+      bf16x8 kfr[2][4];
+      auto load_k = [&](bf16x8* dst, int gi) __attribute__((always_inline)) {
+        const int kb = (KS == 1 ? gi : 2 * kh + gi);
+        const int row = fa16_keymap(kb, c);
+        const int sw = c;                                     // = fa16_kswz(row)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sk + row * 256 + (((4 * ks + g) ^ sw) << 4));
+      };
+      load_k(kfr[0], 0);
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) load_k(kfr[(gi + 1) & 1], gi + 1);
+        if (KS == 1) { issue_k(gi, tn, stn); issue_v(gi, tn, stn); }
+        else { issue_k(2 * gi, tn, stn); issue_k(2 * gi + 1, tn, stn); issue_v(2 * gi, tn, stn); issue_v(2 * gi + 1, tn, stn); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            s[gi][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[gi & 1][ks], qf[qb][ks], s[gi][qb], 0, 0, 0);
+      }
+    }
+    // V^T fragments of the first P.V group (d block 0): requested now, they land under the softmax
+    bf16x8 vfr[2][NKC];
+    auto load_v = [&](bf16x8* dst, int db) __attribute__((always_inline)) {
+      const int d = db * 16 + c;
+      const char* vrow = sv + d * 128;
+      const int sw = (d >> 1) & 7;
+#pragma unroll
+      for (int i = 0; i < NKC; ++i) {
+        const int kc = KS == 1 ? i : kh;
+        dst[i] = *(const bf16x8*)(vrow + (((4 * kc + g) ^ sw) << 4));
+      }
+    };
+    load_v(vfr[0], 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- mask the ragged key tail (last tile only) ----
+    if (t == nt - 1 && (p.Tk & (FA_BK - 1)) != 0) {
+#pragma unroll
+      for (int i = 0; i < 2 * NKC; ++i) {
+        const int kb = KS == 1 ? i : 2 * kh + i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = t * FA_BK + 32 * (kb >> 1) + 8 * g + 4 * (kb & 1) + j;      // fa16_keymap(kb, 4g + j)
+          if (key >= p.Tk) { s[i][0][j] = -1e30f; s[i][1][j] = -1e30f; }
+        }
+      }
+    }
+    // ---- online softmax per query block (key axis = registers x lane groups g) ----
+    float mxc[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mx = s[0][qb][0];
+#pragma unroll
+      for (int i = 0; i < 2 * NKC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = vmax(mx, s[i][qb][j]);
+      mx = lane_xor16_max(mx);
+      mx = lane_xor32_max(mx);
+      mxc[qb] = mx * p.c;
+    }
+    if (__any(mxc[0] - mc_run[0] > FA_DEFER || mxc[1] - mc_run[1] > FA_DEFER)) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float m_new = fmaxf(mc_run[qb], __builtin_ceilf(mxc[qb]));
+        const float alpha = __builtin_amdgcn_exp2f(mc_run[qb] - m_new);
+        mc_run[qb] = m_new;
+        l_run[qb] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[db][qb][j] *= alpha;
+      }
+    }
+    bf16x8 pb[NKC][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float mc = mc_run[qb];
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2 * NKC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i][qb][j], p.c, -mc));
+          psum += e;
+          pb[i >> 1][qb][(i & 1) * 4 + j] = (bf16)e;
+        }
+      l_run[qb] += psum;
+    }
+    // ---- O^T += V^T . P^T: one group per 16-channel block (2 chunks x 2 query blocks), next block's fragments first ----
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      if (db + 1 < 8) load_v(vfr[(db + 1) & 1], db + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NKC; ++i)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[db & 1][i], pb[i][qb], o[db][qb], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float l_tot[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) l_tot[qb] = lane_xor32_sum(lane_xor16_sum(l_run[qb]));
+  if (KS == 2) {
+    // ---- merge the key halves of each wave pair through LDS (the K / V^T ring is dead now) ----
+    __syncthreads();
+    float* xo = (float*)(smem + (wave >> 1) * (17 * 1024));
+    if (kh == 1) {
+#pragma unroll
+      for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xo[((db * 2 + qb) * 4 + j) * 64 + lane] = o[db][qb][j];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) { xo[4096 + qb * 128 + lane] = mc_run[qb]; xo[4096 + qb * 128 + 64 + lane] = l_tot[qb]; }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float m1 = xo[4096 + qb * 128 + lane], l1 = xo[4096 + qb * 128 + 64 + lane];
+      const float m = fmaxf(mc_run[qb], m1);
+      const float a0 = __builtin_amdgcn_exp2f(mc_run[qb] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+      l_tot[qb] = l_tot[qb] * a0 + l1 * a1;
+#pragma unroll
+      for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[db][qb][j] = o[db][qb][j] * a0 + xo[((db * 2 + qb) * 4 + j) * 64 + lane] * a1;
+    }
+  }
+  // ---- epilogue: O[q][d] = O^T[d][q] / l through a wave-private 8 KiB LDS image, whole 256-byte rows out ----
+  if (KS == 1) __syncthreads();
+  char* stg = smem + (KS == 1 ? wave * 8192 : 2 * 17 * 1024 + (wave >> 1) * 8192);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float inv = 1.0f / l_tot[qb];
+    const int row = 16 * qb + c;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      bf16x4v v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (bf16)(o[db][qb][j] * inv);
+      // channels 16db + 4g .. +3 of query row `row`: 16-byte chunk 2db + (g >> 1), half (g & 1)
+      *(bf16x4v*)(stg + row * 256 + (((2 * db + (g >> 1)) ^ (row & 15)) << 4) + (g & 1) * 8) = v;
+    }
+  }
+  {
+    bf16* ob = p.out + ((size_t)b * p.Tq) * p.ldo + h * FA_DH + (lane & 15) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + (lane >> 4);
+      const bf16x8 v = *(const bf16x8*)(stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
+      if (q0 + row < p.Tq) *(bf16x8*)(ob + (size_t)(q0 + row) * p.ldo) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void flash_attn16_kernel(FaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bh, qt;
+  if ((int)blockIdx.x < p.n_full) {
+    fa_map(p, blockIdx.x, bh, qt);
+    fa_body16<1>(p, smem, bh, qt * 128 + wave * FA_QW, 0, wave, lane);
+  } else {
+    const int ti = blockIdx.x - p.n_full;
+    const int tile = p.n_full + ((p.rem & 7) == 0 ? ti % p.rem : ti >> 1);
+    const int half = (p.rem & 7) == 0 ? ti / p.rem : ti & 1;
+    fa_map(p, tile, bh, qt);
+    fa_body16<2>(p, smem, bh, qt * 128 + half * 64 + (wave >> 1) * FA_QW, wave & 1, wave, lane);
+  }
+}
 
 }  // namespace ltxk
 
@@ -484,6 +826,17 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
     p.n_full = tiles - p.rem;
   }
   const dim3 grid((unsigned)(p.n_full + 2 * p.rem));
+  if (LTXK_AB_INT("LTXK_FA_MFMA", FA_DEFAULT_MFMA) == 16) {
+    static thread_local int attr_dev16 = -1;
+    if (dev != attr_dev16) {
+      hipError_t e = hipFuncSetAttribute((const void*)flash_attn16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS);
+      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
+      attr_dev16 = dev;
+    }
+    hipLaunchKernelGGL(flash_attn16_kernel, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
+    LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
+    return LTXK_OK;
+  }
   hipLaunchKernelGGL(flash_attn_kernel<4>, grid, dim3(256), FA_LDS, (hipStream_t)stream, p);
   LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
   return LTXK_OK;

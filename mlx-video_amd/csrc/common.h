@@ -94,6 +94,31 @@ __device__ __forceinline__ void glds16_s(uint64_t base, unsigned lane_off, void*
                : "memory");
 }
 
+// Cross-lane exchanges as single VALU instructions (gfx950: v_permlane32_swap / v_permlane16_swap) instead of the
+// ds_bpermute_b32 that __shfl_xor(x, 32 | 16) compiles to - an LDS instruction with an lgkmcnt wait on the critical path
+// of whatever consumes it.  With both operands a copy of x, after the swap the pair holds (x of this lane, x of lane ^ 32)
+// - resp. lane ^ 16 - in some order, in every lane.
+__device__ __forceinline__ void lane_xor32_pair(float x, float& a, float& b) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void lane_xor16_pair(float x, float& a, float& b) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// v_max_f32 without the canonicalising self-max hipcc puts in front of fmaxf's operands (inputs here are never NaN)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float lane_xor32_max(float x) { float a, b; lane_xor32_pair(x, a, b); return vmax(a, b); }
+__device__ __forceinline__ float lane_xor16_max(float x) { float a, b; lane_xor16_pair(x, a, b); return vmax(a, b); }
+__device__ __forceinline__ float lane_xor32_sum(float x) { float a, b; lane_xor32_pair(x, a, b); return a + b; }
+__device__ __forceinline__ float lane_xor16_sum(float x) { float a, b; lane_xor16_pair(x, a, b); return a + b; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

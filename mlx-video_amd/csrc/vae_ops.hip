@@ -319,6 +319,67 @@ __global__ void tile_blend_finalize_kernel(const float* __restrict__ acc, const 
   out[idx] = (bf16)__fdiv_rn(acc[idx], fmaxf(wsum[b * S + s], 1e-8f));
 }
 
+// ---- area resize of conditioning frames: cv2.resize(..., interpolation=cv2.INTER_AREA) on float frames, DOWNscaling
+// (prepare_video_for_encoding, mlx_video/utils.py:699-705; OpenCV's resizeArea_ / computeResizeAreaTab).  Separable:
+// along each axis destination pixel d covers the source interval [d*scale, (d+1)*scale); a source pixel's weight is the
+// length of its overlap with it divided by min(scale, ssize - d*scale).  One thread per output pixel.
+struct AreaSpan { int s1, s2; float wl, wm, wr; };     // sources s1-1 (weight wl, if > 0), s1 .. s2-1 (wm each), s2 (wr, if > 0)
+__device__ __forceinline__ AreaSpan area_span(int d, double scale, int ssize) {
+  const double f1 = d * scale, f2 = f1 + scale;
+  const double cell = fmin(scale, (double)ssize - f1);
+  int s1 = (int)ceil(f1), s2 = (int)floor(f2);
+  s2 = s2 < ssize - 1 ? s2 : ssize - 1;
+  s1 = s1 < s2 ? s1 : s2;
+  AreaSpan a;
+  a.s1 = s1; a.s2 = s2;
+  a.wl = (s1 - f1 > 1e-3) ? (float)((s1 - f1) / cell) : 0.f;
+  a.wm = (float)(1.0 / cell);
+  a.wr = (f2 - s2 > 1e-3) ? (float)(fmin(fmin(f2 - s2, 1.0), cell) / cell) : 0.f;
+  return a;
+}
+
+template <class T>
+__global__ void resize_area_kernel(const T* __restrict__ x, bf16* __restrict__ out, int64_t planes, int H, int W, int OH, int OW,
+                                   double sy, double sx) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= planes * OH * OW) return;
+  const int ox = (int)(idx % OW);
+  const int oy = (int)((idx / OW) % OH);
+  const int64_t pl = idx / ((int64_t)OW * OH);
+  const AreaSpan ax = area_span(ox, sx, W), ay = area_span(oy, sy, H);
+  const T* src = x + pl * (int64_t)H * W;
+  auto hrow = [&](int y) {                            // horizontal pass of one source row (cv2: buf[dx] += S[sx] * alpha)
+    const T* r = src + (int64_t)y * W;
+    float acc = 0.f;
+    if (ax.wl > 0.f) acc += (float)r[ax.s1 - 1] * ax.wl;
+    for (int s = ax.s1; s < ax.s2; ++s) acc += (float)r[s] * ax.wm;
+    if (ax.wr > 0.f) acc += (float)r[ax.s2] * ax.wr;
+    return acc;
+  };
+  float sum = 0.f;                                    // vertical pass (cv2: sum[dx] += beta * buf[dx])
+  if (ay.wl > 0.f) sum += ay.wl * hrow(ay.s1 - 1);
+  for (int s = ay.s1; s < ay.s2; ++s) sum += ay.wm * hrow(s);
+  if (ay.wr > 0.f) sum += ay.wr * hrow(ay.s2);
+  out[idx] = (bf16)sum;
+}
+
+}  // namespace ltxk
+
+extern "C" int ltxk_resize_area(const void* x, int32_t x_is_f32, void* out, int64_t planes, int32_t H, int32_t W,
+                                int32_t OH, int32_t OW, void* stream) {
+  using namespace ltxk;
+  LTXK_CHECK_ARG(x && out && planes > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "ltxk_resize_area: bad arguments");
+  LTXK_CHECK_ARG(OH <= H && OW <= W, "ltxk_resize_area: %dx%d -> %dx%d is not a downscale (INTER_AREA enlarges by a different rule)", H, W, OH, OW);
+  const int64_t total = planes * OH * OW;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  const double sy = (double)H / OH, sx = (double)W / OW;
+  if (x_is_f32) hipLaunchKernelGGL(resize_area_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (bf16*)out, planes, H, W, OH, OW, sy, sx);
+  else hipLaunchKernelGGL(resize_area_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out, planes, H, W, OH, OW, sy, sx);
+  LTXK_CHECK_LAUNCH("ltxk_resize_area");
+  return LTXK_OK;
+}
+
+namespace ltxk {
 }  // namespace ltxk
 
 using namespace ltxk;

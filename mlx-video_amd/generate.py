@@ -31,6 +31,7 @@ import torch
 
 from .conditioning import (LatentState, VideoConditionByKeyframeIndex, VideoConditionByLatentIndex, apply_conditioning,
                            noise_blend)
+from . import ops
 from .denoise import denoise_dev, denoise_distilled
 from .ltx_model import LTXModel, LTXModelConfig
 from .schedulers import (STAGE_1_SIGMAS, STAGE_2_SIGMAS, _subsample_refinement_sigmas, _subsample_sigmas,
@@ -108,11 +109,13 @@ def _resolve_frame_idx(frame_idx: int, num_frames: int, latent_frames: int) -> i
     return int(max(0, min(latent_frames - 1, int((frame_idx / (num_frames - 1) * (latent_frames - 1)) + 0.5))))
 
 
-def _cond_pixels(src, height: int, width: int, is_video: bool, num_frames: int) -> torch.Tensor:
-    """One conditioning source at one stage's resolution -> (1,3,F,height,width) in [-1,1] (host tensor).
-    Paths go through media.load_image / load_frames (utils.py:529-613: LANCZOS for images, INTER_AREA-like box
-    filter for video frames, frame_cap=num_frames); pixel tensors (1,3,F,H,W) in [-1,1] of another size are
-    resized the way prepare_image_for_encoding / prepare_video_for_encoding do (utils.py:643-715: through uint8)."""
+def _cond_pixels(src, height: int, width: int, is_video: bool, num_frames: int, device=None) -> torch.Tensor:
+    """One conditioning source at one stage's resolution -> (1,3,F,height,width) in [-1,1].
+    Paths go through media.load_image / load_frames on the host (utils.py:529-613: LANCZOS for images, an area filter on
+    the decoded uint8 frames for video, frame_cap=num_frames).  Pixel tensors (1,3,F,H,W) in [-1,1] of another size are
+    resized the way prepare_image_for_encoding / prepare_video_for_encoding do (utils.py:643-715): images through uint8 +
+    LANCZOS on the host (one frame); VIDEO frames with cv2.INTER_AREA on the float frames - here the HIP kernel
+    ltxk_resize_area on the device (65 frames of 768x768 cost 1.0 s as a host loop, config 5), bf16 out."""
     from . import media
     if isinstance(src, (str, Path)):
         if is_video:
@@ -122,12 +125,16 @@ def _cond_pixels(src, height: int, width: int, is_video: bool, num_frames: int) 
         src = torch.from_numpy(src)
     if not torch.is_tensor(src) or src.dim() != 5 or src.shape[1] != 3:
         raise ValueError("conditioning source must be a path, or a (1,3,F,H,W) pixel tensor in [-1,1]")
-    t = src.detach().to("cpu", torch.float32)
+    t = src.detach()
     if is_video:
         t = t[:, :, :num_frames]
         t = t[:, :, : 1 + ((t.shape[2] - 1) // 8) * 8]            # the encoder takes 1+8k frames (video_vae.py:332-337)
     if tuple(t.shape[-2:]) == (height, width):
         return t
+    if is_video and height <= t.shape[-2] and width <= t.shape[-1] and device is not None:
+        td = t.to(device)
+        return ops.resize_area(td if td.dtype in (torch.float32, BF16) else td.float(), height, width)
+    t = t.to("cpu", torch.float32)
     frames01 = ((t[0].permute(1, 2, 3, 0) + 1.0) / 2.0).clamp(0, 1).numpy()        # (F,H,W,3) in [0,1]
     return media.resize_conditioning(frames01, height, width, is_video)
 
@@ -143,7 +150,7 @@ def _encode_conditionings(items, encoder: Optional[VideoEncoder], height: int, w
         else:
             if encoder is None:
                 raise ValueError("pixel conditioning needs a VAE encoder (pass vae_encoder= or a model_repo with VAE encoder weights)")
-            t = encoder(_cond_pixels(src, height, width, is_video, num_frames).to(device).to(BF16))
+            t = encoder(_cond_pixels(src, height, width, is_video, num_frames, device).to(device).to(BF16))
         idx = _resolve_frame_idx(int(frame_idx), num_frames, latent_frames)
         out.append(VideoConditionByKeyframeIndex(t, idx, float(strength)) if guide
                    else VideoConditionByLatentIndex(t, idx, float(strength)))
@@ -430,9 +437,13 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--tiling", type=str, default="auto")
     ap.add_argument("--stage1-steps", type=int, default=None)
     ap.add_argument("--stage2-steps", type=int, default=None)
-    ap.add_argument("--sigma-subsample", choices=["uniform", "farthest"], default="farthest")
-    ap.add_argument("--compile", dest="compile_step", action="store_true", default=None)
-    ap.add_argument("--cfg-batch", action="store_true", default=None)
+    ap.add_argument("--sigma-subsample", choices=["uniform", "farthest"], default=__import__("os").getenv("LTX_SIGMA_SUBSAMPLE", "farthest"))
+    ap.add_argument("--eval-interval", type=int, default=None, help="Host sync cadence of the denoise loop (default: auto)")
+    ap.add_argument("--compile", dest="compile_step", action="store_true", default=False,
+                    help="Captured step (the reference's mx.compile'd step: bf16-rounded sigmas in x0 and Euler)")
+    ap.add_argument("--no-compile", action="store_true", help="Disable the compiled step even if LTX_COMPILE enables it")
+    ap.add_argument("--cfg-batch", action="store_true", default=False, help="CFG pair as one B=2 forward")
+    ap.add_argument("--no-cfg-batch", action="store_true", help="Two sequential forwards even if LTX_CFG_BATCH enables batching")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--profile-json", type=str, default=None)
     ap.add_argument("--prompt-embeds", type=str, default=None, help=".pt/.npy file with (1,1024,3840) text embeddings")
@@ -442,18 +453,46 @@ def build_parser() -> argparse.ArgumentParser:
     return ap
 
 
-def main(argv: Optional[Sequence[str]] = None) -> None:
-    args = build_parser().parse_args(argv)
+def resolve_cli_heuristics(args, env=None):
+    """The auto rules of generate.py:4545-4560 and 4629-4644 that pick the hot path's flavour: step counts, the host sync
+    cadence, compiled-vs-eager step (they differ in the sigma the Euler update sees, generate.py:1170-1174 vs 1293-1301)
+    and batched-vs-sequential CFG.  Pure function of the parsed args and the environment (LTX_COMPILE, LTX_CFG_BATCH,
+    LTX_EVAL_INTERVAL); mutates and returns ``args``."""
+    env = __import__("os").environ if env is None else env
+    truthy = lambda name: str(env.get(name, "")).lower() in ("1", "true", "yes")
     is_dev = args.pipeline == "dev"
-    # CLI heuristics of generate.py:4545-4552,4629-4644
     if args.stage1_steps is None:
         args.stage1_steps = 5 if args.pipeline == "distilled" else 8
     if args.stage2_steps is None:
         args.stage2_steps = 1 if args.pipeline == "distilled" else 3
-    if args.compile_step is None:
-        args.compile_step = is_dev and args.steps >= 8
-    if args.cfg_batch is None:
-        args.cfg_batch = is_dev and args.cfg_scale > 1.0
+    if args.eval_interval is None:
+        ev = env.get("LTX_EVAL_INTERVAL")
+        args.eval_interval = int(ev) if ev is not None else (2 if is_dev else 4)
+    if args.eval_interval < 1:
+        args.eval_interval = 1
+    repo_l = str(getattr(args, "model_repo", None) or "").lower()
+    is_quant_repo = any(tag in repo_l for tag in ("4bit", "8bit", "q4", "q8", "int4", "int8"))
+    if getattr(args, "no_compile", False):
+        args.compile_step = False
+    elif truthy("LTX_COMPILE"):
+        args.compile_step = True
+    elif not args.compile_step:
+        if is_dev and args.steps >= 8:
+            args.compile_step = True
+        elif (not is_dev) and args.num_frames >= 97 and (args.stage1_steps + args.stage2_steps) >= 5:
+            args.compile_step = True
+    if getattr(args, "no_cfg_batch", False):
+        args.cfg_batch = False
+    elif truthy("LTX_CFG_BATCH"):
+        args.cfg_batch = True
+    elif not args.cfg_batch and is_dev and args.cfg_scale > 1.0 and not is_quant_repo:
+        args.cfg_batch = True
+    return args
+
+
+def main(argv: Optional[Sequence[str]] = None) -> None:
+    args = resolve_cli_heuristics(build_parser().parse_args(argv))
+    is_dev = args.pipeline == "dev"
     dev = torch.device("cuda:0")
     kw = {}
     # generate.py:4667-4694: --image items without an explicit index/strength take --image-frame-idx / --image-strength
@@ -488,6 +527,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
                    negative_prompt=args.negative_prompt, height=args.height, width=args.width, num_frames=args.num_frames,
                    num_inference_steps=args.steps, cfg_scale=args.cfg_scale, seed=args.seed, fps=args.fps,
                    output_path=args.output_path, tiling=args.tiling, compile_step=args.compile_step, cfg_batch=args.cfg_batch,
+                   eval_interval=args.eval_interval,
                    profile=args.profile, profile_json_path=args.profile_json, stage1_steps=args.stage1_steps,
                    stage2_steps=args.stage2_steps, sigma_subsample=args.sigma_subsample, verbose=True, device=dev,
                    images=images, video_conditionings=videos, loras=args.lora, distilled_loras=args.distilled_lora,

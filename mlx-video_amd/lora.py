@@ -63,31 +63,55 @@ def load_lora_state(path: Path) -> Dict[str, torch.Tensor]:
 def merge_lora_pair(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, strength: float) -> torch.Tensor:
     """w (out,in), A (r,in), B (out,r) bf16 on the device -> bf16(w + bf16(strength * B@A)).
     The rank axis is zero-padded to a multiple of 64 (the GEMM's K-step); zeros add nothing."""
-    r = A.shape[0]
+    Bp, At = _pack_group([A], [B], w.device)
+    return ops.gemm(Bp[0], At[0], None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(), alpha=float(strength))
+
+
+def _pack_group(As, Bs, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """G pairs of one shape -> the two GEMM operand stacks on the device, built with ONE host->device copy and ONE
+    pad / transpose kernel each (not per pair): Bp (G,out,rp) and A^T (G,in,rp), rank zero-padded to rp = 64*ceil(r/64)."""
+    r = As[0].shape[0]
     rp = (r + 63) // 64 * 64
-    Bp = torch.zeros((B.shape[0], rp), dtype=BF16, device=w.device)
-    Bp[:, :r] = B.to(BF16)
-    At = torch.zeros((A.shape[1], rp), dtype=BF16, device=w.device)
-    At[:, :r] = A.to(BF16).t()
-    return ops.gemm(Bp, At, None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(), alpha=float(strength))
+    A_all = torch.stack([a.to(BF16) for a in As]).to(device, non_blocking=True)          # (G,r,in)
+    B_all = torch.stack([b.to(BF16) for b in Bs]).to(device, non_blocking=True)          # (G,out,r)
+    if rp == r:
+        return B_all.contiguous(), A_all.transpose(1, 2).contiguous()
+    Bp = torch.zeros((B_all.shape[0], B_all.shape[1], rp), dtype=BF16, device=device)
+    Bp[:, :, :r] = B_all
+    At = torch.zeros((A_all.shape[0], A_all.shape[2], rp), dtype=BF16, device=device)
+    At[:, :, :r] = A_all.transpose(1, 2)
+    return Bp, At
+
+
+GROUP_MAX = 64      # pairs packed per host->device copy (bounds the staging memory: 64 x (16384+4096) x 128 x 2 B = 336 MB)
 
 
 def apply_lora_to_weights(weights: Dict[str, torch.Tensor], lora_specs: Iterable[LoraSpec], verbose: bool = False,
                           lora_states: Dict[Path, Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
-    """lora.py:94-127.  ``lora_states`` lets callers pass already-loaded LoRA tensors."""
+    """lora.py:94-127.  ``lora_states`` lets callers pass already-loaded LoRA tensors.  Pairs of one (A, B) shape are
+    packed together (one copy + one pad/transpose kernel per group), then merged with one EPI_SCALE_RES GEMM launch per
+    weight; a weight touched by several LoRAs is merged in spec order, as the reference does."""
     updated = dict(weights)
     for spec in lora_specs:
         sd = (lora_states or {}).get(spec.path) or load_lora_state(spec.path)
         applied = skipped = 0
+        groups: Dict[tuple, list] = {}
         for base_raw, base_san, A, B in _iter_lora_pairs(sd):
             key = next((k for k in _candidate_weight_keys(base_raw, base_san) if k in updated), None)
             if key is None:
                 skipped += 1
                 continue
-            w = updated[key]
-            dev = w.device
-            updated[key] = merge_lora_pair(w, A.to(dev), B.to(dev), spec.strength).reshape(w.shape)
-            applied += 1
+            groups.setdefault((tuple(A.shape), tuple(B.shape), str(updated[key].device)), []).append((key, A, B))
+        for items in groups.values():
+            for c0 in range(0, len(items), GROUP_MAX):
+                chunk = items[c0:c0 + GROUP_MAX]
+                dev = updated[chunk[0][0]].device
+                Bp, At = _pack_group([a for _, a, _ in chunk], [b for _, _, b in chunk], dev)
+                for i, (key, _, _) in enumerate(chunk):
+                    w = updated[key]
+                    updated[key] = ops.gemm(Bp[i], At[i], None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(),
+                                            alpha=float(spec.strength)).reshape(w.shape)
+                    applied += 1
         if verbose:
             print(f"[LoRA] {spec.path} applied={applied} skipped={skipped}")
         elif applied == 0:

@@ -278,3 +278,16 @@ def euler_only(latent: torch.Tensor, denoised: torch.Tensor, sigma: float, sigma
     check(_lib.load().ltxk_euler_step(_p(latent.contiguous()), _p(denoised.contiguous()), _p(out), latent.numel(),
                                       sigma, sigma_next, _stream()), "ltxk_euler_step")
     return out
+
+
+def resize_area(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
+    """(..., H, W) fp32 / bf16 device tensor -> (..., oh, ow) bf16: cv2.INTER_AREA downscale of every (H,W) plane
+    (prepare_video_for_encoding, utils.py:699-705)."""
+    if not x.is_cuda or x.dtype not in (torch.float32, BF16):
+        raise _lib.LtxkError("resize_area: expected a float32 / bfloat16 device tensor")
+    x = x.contiguous()
+    H, W = x.shape[-2:]
+    planes = x.numel() // (H * W)
+    out = torch.empty(tuple(x.shape[:-2]) + (oh, ow), dtype=BF16, device=x.device)
+    check(_lib.load().ltxk_resize_area(_p(x), int(x.dtype == torch.float32), _p(out), planes, H, W, oh, ow, _stream()), "ltxk_resize_area")
+    return out

@@ -350,3 +350,37 @@ def test_vae_statistics_keys_match_exactly(tmp_path):
     r3 = collections.OrderedDict([("latents_mean", f(5)), ("per_channel_statistics.mean", f(9)), ("latents_std", f(6))])
     d3 = weights.vae_decoder_weights(r3, "cpu")
     assert float(d3["latents_mean"][0]) == 5.0 and float(d3["latents_std"][0]) == 6.0
+
+
+def test_cli_heuristics_table():
+    """generate.py:4545-4560,4629-4644: which flavour of the hot loop the CLI picks (compiled vs eager step, batched vs
+    sequential CFG, sync cadence, step counts) from flags and LTX_COMPILE / LTX_CFG_BATCH / LTX_EVAL_INTERVAL."""
+    from mlx_video_amd.generate import build_parser, resolve_cli_heuristics
+
+    def run(argv, env=None):
+        return resolve_cli_heuristics(build_parser().parse_args(argv), env or {})
+
+    a = run(["--pipeline", "dev"])                                   # dev, 40 steps, cfg 4.0
+    assert (a.compile_step, a.cfg_batch, a.eval_interval, a.stage1_steps, a.stage2_steps) == (True, True, 2, 8, 3)
+    a = run(["--pipeline", "dev", "--steps", "7"])                   # short dev loop: no auto compile
+    assert (a.compile_step, a.cfg_batch) == (False, True)
+    a = run(["--pipeline", "dev", "--cfg-scale", "1.0"])             # no CFG -> nothing to batch
+    assert (a.compile_step, a.cfg_batch) == (True, False)
+    a = run(["--pipeline", "dev", "--no-compile", "--no-cfg-batch"], {"LTX_COMPILE": "1", "LTX_CFG_BATCH": "1"})
+    assert (a.compile_step, a.cfg_batch) == (False, False)           # the --no-* flags beat the environment
+    a = run(["--pipeline", "dev", "--steps", "4", "--cfg-scale", "1.0"], {"LTX_COMPILE": "true", "LTX_CFG_BATCH": "yes"})
+    assert (a.compile_step, a.cfg_batch) == (True, True)             # the environment beats the auto rules
+    a = run(["--pipeline", "dev", "--model-repo", "org/LTX-2-dev-4bit"])
+    assert a.cfg_batch is False                                      # quantised repos never auto-batch
+    a = run(["--pipeline", "distilled"])
+    assert (a.compile_step, a.cfg_batch, a.eval_interval, a.stage1_steps, a.stage2_steps) == (False, False, 4, 5, 1)
+    a = run(["--pipeline", "distilled", "--num-frames", "97", "--stage1-steps", "4"])      # 4 + 1 >= 5 and a long clip
+    assert a.compile_step is True
+    a = run(["--pipeline", "distilled", "--num-frames", "97", "--stage1-steps", "3"])
+    assert a.compile_step is False
+    a = run(["--pipeline", "keyframe"]) if "keyframe" in [c for c in build_parser()._option_string_actions["--pipeline"].choices] else None
+    if a is not None:
+        assert (a.stage1_steps, a.stage2_steps, a.eval_interval) == (8, 3, 4)
+    assert run(["--pipeline", "dev"], {"LTX_EVAL_INTERVAL": "7"}).eval_interval == 7
+    assert run(["--pipeline", "dev", "--eval-interval", "0"]).eval_interval == 1
+    assert run(["--pipeline", "dev", "--eval-interval", "3"], {"LTX_EVAL_INTERVAL": "7"}).eval_interval == 3

@@ -174,3 +174,17 @@ def test_bf16_policy_close_to_fp32_on_tiny_model():
     b = O.ltx_forward(lat, ts, ctx, pe, W, cfg, O.BF16)
     assert a.shape == (1, 8, 128)
     assert float((a - b).norm() / a.norm()) < 3e-2
+
+
+def test_area_resize_restatement_known_answers():
+    """oracle/media.py (OpenCV INTER_AREA, utils.py:699-705): weights of every destination pixel sum to 1; integer factors
+    are the plain block mean; a constant image stays constant; the 3 -> 2 table is the textbook [1, .5 | .5, 1] / 1.5."""
+    import numpy as np
+    from oracle import media as OM
+    for ss, ds in ((12, 8), (768, 384), (50, 33), (7, 7), (100, 1)):
+        A = OM.area_weights(ss, ds)
+        assert np.allclose(A.sum(1), 1.0, atol=1e-6) and (A >= 0).all()
+    assert np.allclose(OM.area_weights(3, 2), np.array([[2 / 3, 1 / 3, 0], [0, 1 / 3, 2 / 3]], np.float32), atol=1e-7)
+    x = np.random.default_rng(0).random((2, 3, 8, 12), dtype=np.float32)
+    assert np.allclose(OM.resize_area(x, 4, 6), x.reshape(2, 3, 4, 2, 6, 2).mean((3, 5)), atol=1e-6)
+    assert np.allclose(OM.resize_area(np.full((5, 9), 0.37, np.float32), 3, 4), 0.37, atol=1e-6)

@@ -326,3 +326,33 @@ def test_conv3d_short_last_round_as_half_tiles(dev, res, cout, shape, monkeypatc
         torch.cuda.synchronize()
     assert torch.equal(outs["0"], outs["1"])
     assert float(outs["1"].float().abs().mean()) > 0.05
+
+
+@pytest.mark.parametrize("shape,out", [((3, 5, 64, 96), (32, 48)), ((2, 2, 96, 144), (64, 96)), ((1, 3, 50, 70), (20, 33)),
+                                       ((1, 1, 33, 40), (33, 40)), ((1, 2, 768, 768), (384, 384))])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_resize_area_vs_oracle(dev, shape, out, dt):
+    """ltxk_resize_area (cv2.INTER_AREA on float frames, prepare_video_for_encoding utils.py:699-705) against the numpy
+    restatement of OpenCV's area table (oracle/media.py): integer factors (closed form: the block mean), fractional factors
+    (1.5x, 2.5x / 2.12x: parity unpinned beyond the restatement - cv2 is not installed), identity."""
+    import numpy as np
+    from oracle import media as OM
+    from mlx_video_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(*shape, generator=g) * 2 - 1
+    if dt == "bf16":
+        x = x.to(torch.bfloat16)
+    got = ops.resize_area(x.to(dev), *out)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(OM.resize_area(x.float().numpy(), *out)).to(torch.bfloat16)
+    assert got.shape == ref.shape and got.dtype == torch.bfloat16
+    d = (got.float().cpu() - ref.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2 ** -7          # fp32 order: rare single-ulp bf16 flips
+    H, W = shape[-2:]
+    if H % out[0] == 0 and W % out[1] == 0:           # known answer: the plain block mean
+        fy, fx = H // out[0], W // out[1]
+        mean = x.float().reshape(*shape[:-2], out[0], fy, out[1], fx).mean((-3, -1)).to(torch.bfloat16)
+        dm = (got.float().cpu() - mean.float()).abs()
+        assert float((dm > 0).float().mean()) < 2e-3 and float(dm.max()) <= 2 ** -7
+    with pytest.raises(Exception, match="not a downscale"):
+        ops.resize_area(x.to(dev), shape[-2] + 1, shape[-1])
