@@ -390,6 +390,393 @@ __global__ void conv_splitk_finalize_kernel(const float* __restrict__ slab, cons
   *(bf16x4*)(out + e) = o;
 }
 
+// =====================================================================================================================
+// kw-reuse form (round 3).  The three taps kw = 0,1,2 of one (kd, kh) read the SAME image row shifted by one voxel, but the
+// kernel above fetches the 256-row A tile afresh for each of the 27 taps.  Here a stage holds, for one (kd, kh) and one
+// 32-channel block, a PANEL of the tile's voxel rows plus one halo voxel on either side of every image row the tile
+// touches (tile row i of run r sits at panel row i + 2r + 1); tap kw reads panel rows shifted by kw.  A stage is then
+//   A panel  (BM + 2*runs) x 64 B  =  17 KiB            (was 3 taps x 32 KiB per 64 channels: -65 % A bytes through LDS-DMA)
+//   W        3 taps x 128 rows x 64 B  =  24 KiB
+// and feeds 3 MFMA sub-steps (v_mfma_f32_16x16x32_bf16: 32 channels each) = 48 MFMAs per wave per barrier (was 32), with
+// 41 KiB of LDS-DMA per stage against 48 KiB per 64-channel K-step: 0.85 KiB per MFMA instead of 1.5.  The MFMA power
+// probe prices every 1-KiB LDS-DMA piece at ~30 matrix-pipe cycles plus clock.
+// K is walked (kd, kh) -> 32-channel block -> kw: another summation order than the kernel above (same rounding points).
+// LDS rows are 64 B; the 16-byte chunk index is XOR-ed with 2*((row >> 2) & 1): conflict-free ds_read_b128 for ANY 16
+// consecutive rows (the panel rows of an MFMA block start at an arbitrary offset).
+// Used for the 27-tap convolution when W >= 64 (at most BM/64 + 1 image rows per tile), no split-K, no fused activation.
+// =====================================================================================================================
+constexpr int KW_BN = 128;
+template <int TT>
+struct KwGeom {
+  static constexpr int BM = 64 * TT;                 // 4 wave rows x TT MFMA row blocks
+  static constexpr int RUNMAX = BM / 64 + 1;         // image rows a tile can touch when W >= 64
+  static constexpr int PR = BM + 2 * RUNMAX;         // panel rows
+  static constexpr int A_PIECES = (PR + 15) / 16;    // 1-KiB pieces of 16 rows x 64 B
+  static constexpr int APW = (A_PIECES + 7) / 8;     // per wave (the last ones re-issue the final piece)
+  static constexpr int A_BYTES = A_PIECES * 1024;
+  static constexpr int W_BYTES = 3 * KW_BN * 64;
+  static constexpr int STAGE = A_BYTES + W_BYTES;
+  static constexpr int LDS = 3 * STAGE;
+  static constexpr int PER_STAGE = 3 + APW;
+};
+
+// Rotated software pipeline of a stage with three MFMA sub-steps (kw = 0,1,2), after MmaPipe (gemm_core.h): the 3*TT MFMA
+// groups (one A row block x 4 W column blocks) run in a fixed order pinned by sched_barrier; fragment ds_read_b128s are
+// issued one group ahead of their use (flat order W0, A0[*], W1, A1[*], W2, A2[*]); the stage's LDS-DMA pieces are
+// sprinkled one per group; and the last two groups of every stage are deferred until after the next barrier (their
+// operands are in registers), so they execute while the first fragment reads of the new stage are in flight.
+template <int TT, int NPIECES>
+struct KwPipe {
+  static constexpr int NS = 3, PD = 1, DG = 2;
+  static constexpr int NG = NS * TT, RPS = 4 + TT, TOTAL = NS * RPS;
+  static constexpr int PPG = (NPIECES + NG - 1) / NG;
+  static_assert(TT >= 2, "deferred groups must lie in the last sub-step");
+  bf16x8 wf[NS][4], af[NS][TT];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wf[NS - 1][i][j] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[NS - 1][i][j] = (bf16)0.f;
+  }
+  static __device__ __forceinline__ void group(const bf16x8& a, const bf16x8 (&w)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], a, acc[nt], 0, 0, 0);
+  }
+  template <class RdFn, class IssueFn>
+  __device__ __forceinline__ void step(RdFn&& rdf, IssueFn&& issue, f32x4 (&acc)[TT][4]) {
+    auto rd = [&](int idx) __attribute__((always_inline)) {
+      const int ks = idx / RPS, r = idx % RPS;
+      if (r < 4) wf[ks][r] = rdf(ks, r);
+      else af[ks][r - 4] = rdf(ks, r);
+    };
+    auto need = [](int g) { return g < 0 ? 0 : (g >= NG ? TOTAL : (g / TT) * RPS + 4 + (g % TT) + 1); };
+    int issued = 0;
+#pragma unroll
+    for (int v = 0; v < DG; ++v) {                      // the groups deferred from the previous stage
+      int target = need(v - DG + PD);
+      if (target > (NS - 1) * RPS) target = (NS - 1) * RPS;     // the last sub-step's registers still feed the deferred groups
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i)
+        if (i >= issued && i < target) rd(i);
+      issued = target > issued ? target : issued;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q) issue(v * PPG + q);
+      group(af[NS - 1][TT - DG + v], wf[NS - 1], acc[TT - DG + v]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG - DG; ++g) {
+      const int target = need(g + PD);
+#pragma unroll
+      for (int i = 0; i < TOTAL; ++i)
+        if (i >= issued && i < target) rd(i);
+      issued = target > issued ? target : issued;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q) issue((g + DG) * PPG + q);
+      group(af[g / TT][g % TT], wf[g / TT], acc[g % TT]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < TOTAL; ++i)
+      if (i >= issued) rd(i);
+  }
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TT][4]) {
+#pragma unroll
+    for (int v = 0; v < DG; ++v) group(af[NS - 1][TT - DG + v], wf[NS - 1], acc[TT - DG + v]);
+  }
+};
+
+__device__ __forceinline__ int kw_swz(int row) { return 2 * ((row >> 2) & 1); }
+
+template <int TT, bool RES>
+__global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kw_kernel(ConvParams p) {
+  using G = KwGeom<TT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, g = lane >> 4;
+  int tile;
+  {
+    const int nt_all = p.RT * p.CT, q = nt_all >> 3, r = nt_all & 7;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tile = p.xcd_order ? x * q + (x < r ? x : r) + j : (int)blockIdx.x;
+  }
+  const int ct = tile % p.CT, rt = tile / p.CT;
+  const int m0 = p.m_base + rt * G::BM, n0 = ct * KW_BN;
+  const int Wd = p.W;
+  const int w0 = m0 % Wd, vr0 = m0 / Wd;             // column / image-row id (over B*D*H) of the tile's first voxel
+  const int nrows_img = p.B * p.D * p.H;
+  const unsigned rowB = (unsigned)p.Cin * 2u;
+  const int lrow4 = lane >> 2, slot4 = lane & 3;
+
+  // ---- bias first: older than every LDS-DMA piece, so the counted vmcnt waits below cover it ----
+  const int nq = g * 4;
+  bf16x4 bpre[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    int n = n0 + wn * 64 + nt * 16 + nq;
+    n = n < p.Cout ? n : p.Cout - 4;
+    bpre[nt] = *opaque_gptr<bf16x4>((const bf16x4*)(p.bias + n));
+  }
+
+  // ---- W loader: piece i = tap kw of this (kd, kh), weight rows 16*wave .. +15 of the column tile ----
+  int co = n0 + wave * 16 + lrow4;
+  co = co < p.Cout ? co : p.Cout - 1;
+  const char* wsrc = (const char*)(p.w + (size_t)co * 27 * p.Cin) + ((slot4 ^ kw_swz(wave * 16 + lrow4)) << 4);
+
+  // ---- A loader: panel pieces wave, wave + 8, ... ; per panel row the separable source offsets (as in the kernel above) ----
+  unsigned od[G::APW][3], oh[G::APW][3], owf[G::APW], zbits[G::APW];
+  int adst[G::APW];
+#pragma unroll
+  for (int i = 0; i < G::APW; ++i) {
+    int piece = wave + 8 * i;
+    piece = piece < G::A_PIECES ? piece : G::A_PIECES - 1;
+    const int prow = piece * 16 + lrow4;
+    // run of this panel row: run r covers tile rows [S, E) and panel rows [S + 2r, E + 2r + 2)
+    int r = 0, S = 0, E = Wd - w0 < G::BM ? Wd - w0 : G::BM;
+#pragma unroll
+    for (int rr = 0; rr < G::RUNMAX - 1; ++rr) {
+      if (prow >= E + 2 * r + 2 && E < G::BM) {
+        S = E;
+        E = S + Wd < G::BM ? S + Wd : G::BM;
+        ++r;
+      }
+    }
+    int j = prow - (S + 2 * r);
+    j = j < E - S + 1 ? j : E - S + 1;                  // rows past the panel's end repeat its last row
+    int wq = (r == 0 ? w0 : 0) - 1 + j;                 // column of the source voxel: -1 and W are the halo
+    int vr = vr0 + r;
+    vr = vr < nrows_img ? vr : nrows_img - 1;
+    const int vh = vr % p.H, vd = (vr / p.H) % p.D, vb = vr / (p.H * p.D);
+    unsigned zb = 0;
+    if (wq < 0 || wq >= Wd) {
+      if (p.pad_mode == LTXK_PAD_REFLECT) wq = wq < 0 ? 1 : Wd - 2;
+      else { zb |= 512u; wq = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int d = vd + k - (p.causal == 1 ? 2 : 1);
+      if (p.causal == 2) {
+        if (d < 0 || d >= p.D) { zb |= 64u << k; d = 0; }
+      } else {
+        d = d < 0 ? 0 : (d >= p.D ? p.D - 1 : d);
+      }
+      int h = vh + k - 1;
+      if (p.pad_mode == LTXK_PAD_REFLECT) {
+        h = h < 0 ? 1 : (h >= p.H ? p.H - 2 : h);
+      } else if (h < 0 || h >= p.H) {
+        zb |= 1u << k; h = 0;
+      }
+      od[i][k] = (unsigned)((vb * p.D + d) * p.H) * (unsigned)Wd * rowB;
+      oh[i][k] = (unsigned)(h * Wd) * rowB;
+    }
+    owf[i] = (unsigned)wq * rowB + ((unsigned)(slot4 ^ kw_swz(prow)) << 4);
+    zbits[i] = zb;
+    adst[i] = piece * 1024;
+  }
+  const char* zsrc = (const char*)p.zero + slot4 * 16;
+  const char* xb = (const char*)p.x;
+  unsigned off_grp[G::APW];
+  bool zgrp[G::APW];
+  auto set_group = [&](int gi) __attribute__((always_inline)) {       // gi = kd * 3 + kh
+    const int kd = gi / 3, kh = gi - 3 * kd;
+    const unsigned d0 = kd == 0 ? ~0u : 0u, d1 = kd == 1 ? ~0u : 0u, d2 = kd == 2 ? ~0u : 0u;
+    const unsigned h0 = kh == 0 ? ~0u : 0u, h1 = kh == 1 ? ~0u : 0u, h2 = kh == 2 ? ~0u : 0u;
+#pragma unroll
+    for (int j = 0; j < G::APW; ++j) {
+      off_grp[j] = ((od[j][0] & d0) | (od[j][1] & d1) | (od[j][2] & d2)) + ((oh[j][0] & h0) | (oh[j][1] & h1) | (oh[j][2] & h2)) + owf[j];
+      zgrp[j] = ((zbits[j] >> kh) & 1u) | ((zbits[j] >> (6 + kd)) & 1u) | ((zbits[j] >> 9) & 1u);
+    }
+  };
+  // i-th LDS-DMA piece of this wave for stage (group gi, 32-channel block cb) into ring slot s
+  auto issue_piece = [&](int i, int gi, int cb, int s) __attribute__((always_inline)) {
+    char* base = smem + s * G::STAGE;
+    if (i < 3) {
+      glds16(wsrc + ((size_t)(gi * 3 + i) * p.Cin + cb * 32) * 2, base + G::A_BYTES + i * (KW_BN * 64) + wave * 1024);
+    } else if (i < G::PER_STAGE) {
+      const int j = i - 3 < G::APW ? i - 3 : 0;
+      const char* src = zgrp[j] ? zsrc : xb + (size_t)(off_grp[j] + (unsigned)cb * 64u);
+      glds16(src, base + adst[j]);
+    }
+  };
+
+  // ---- fragment addresses (stage-invariant): A = panel rows of the wave's TT row blocks for kw = 0,1,2; W rows of its 4 column blocks ----
+  unsigned aaddr[TT][3], waddr[4];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int i = wm * TT * 16 + tt * 16 + c;
+    const int pb = i + 2 * ((w0 + i) / Wd);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) aaddr[tt][kw] = (unsigned)((pb + kw) * 64 + ((g ^ kw_swz(pb + kw)) << 4));
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int row = wn * 64 + nt * 16 + c;
+    waddr[nt] = (unsigned)(G::A_BYTES + row * 64 + ((g ^ kw_swz(row)) << 4));
+  }
+
+  f32x4 acc[TT][4];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cpb = p.Cin / 32;
+  const int nk = 9 * cpb;
+  int pgi = 0, pcb = 0;                                   // (group, channel block) of the prefetch stream
+  set_group(0);
+#pragma unroll
+  for (int i = 0; i < G::PER_STAGE; ++i) issue_piece(i, 0, 0, 0);
+  ++pcb;
+  if (pcb == cpb) { pcb = 0; ++pgi; set_group(pgi); }
+#pragma unroll
+  for (int i = 0; i < G::PER_STAGE; ++i) issue_piece(i, pgi, pcb, 1);
+
+  bf16x4 rres[RES ? TT : 1][4];
+  int slot = 0;
+  KwPipe<TT, G::PER_STAGE> pipe;
+  pipe.init();
+  auto stage = [&](auto mode_c) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_c)::value;         // 0: steady state; 1: next-to-last (nothing left to request); 2: last
+    if constexpr (MODE == 2) wait_keep_and_barrier<0>();
+    else wait_keep_and_barrier<G::PER_STAGE>();
+    int s2 = slot + 2;
+    s2 = s2 >= 3 ? s2 - 3 : s2;
+    if constexpr (MODE == 0) {
+      ++pcb;
+      if (pcb == cpb) { pcb = 0; ++pgi; set_group(pgi); }
+    }
+    if constexpr (MODE == 2 && RES) {
+      // the residual tile is requested behind the last barrier (no LDS-DMA is in flight any more) and lands under this
+      // stage's 48 MFMAs
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        int m = m0 + wm * TT * 16 + tt * 16 + c;
+        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          int n = n0 + wn * 64 + nt * 16 + nq;
+          n = n < p.Cout ? n : p.Cout - 4;
+          rres[tt][nt] = *opaque_gptr<bf16x4>((const bf16x4*)(p.resid + (size_t)m * p.Cout + n));
+        }
+      }
+    }
+    const char* st = smem + slot * G::STAGE;
+    pipe.step([&](int ks, int r) __attribute__((always_inline)) -> bf16x8 {
+                return r < 4 ? *(const bf16x8*)(st + waddr[r] + ks * (KW_BN * 64)) : *(const bf16x8*)(st + aaddr[r - 4 < TT ? r - 4 : 0][ks]);
+              },
+              [&](int i) __attribute__((always_inline)) {
+                if constexpr (MODE == 0) issue_piece(i, pgi, pcb, s2);
+              },
+              acc);
+    slot = slot + 1 == 3 ? 0 : slot + 1;
+  };
+  for (int s = 0; s < nk - 2; ++s) stage(IntC<0>{});
+  stage(IntC<1>{});
+  stage(IntC<2>{});
+  pipe.finish(acc);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre[nt]));
+
+  // ---- epilogue (as the kernel above): y = bf16(acc + bias) [+ resid], through a wave-private LDS image, whole lines out ----
+  const bool wide = (p.Cout & 7) == 0;
+  char* stg = smem + wave * (TT * 16 * 128);
+  if (wide) __syncthreads();
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int m = m0 + wm * TT * 16 + tt * 16 + c;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + nq;
+      if (n >= p.Cout) continue;
+      float y[4];
+      const bf16x4 b = bpre[nt];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = rbf(acc[tt][nt][j] + (float)b[j]);
+      if constexpr (RES) {
+        const bf16x4 r = rres[tt][nt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = rbf(y[j] + (float)r[j]);
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+      if (wide) {
+        const int r = tt * 16 + c;
+        *(bf16x4*)(stg + r * 128 + (((nt * 2 + (g >> 1)) ^ (r & 7)) << 4) + (g & 1) * 8) = o;
+      } else {
+        *(bf16x4*)(p.out + (size_t)m * p.Cout + n) = o;
+      }
+    }
+  }
+  if (wide) {
+    const int cc = lane & 7;
+    const int n = n0 + wn * 64 + cc * 8;
+#pragma unroll
+    for (int i = 0; i < TT * 2; ++i) {
+      const int r = i * 8 + (lane >> 3);
+      const int m = m0 + wm * TT * 16 + r;
+      const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((cc ^ (r & 7)) << 4));
+      if (m < p.M && n < p.Cout) *(bf16x8*)(p.out + (size_t)m * p.Cout + n) = v;
+    }
+  }
+}
+
+template <int TT, bool RES>
+static int conv_launch_kw(const ConvParams& p0, hipStream_t stream) {
+  using G = KwGeom<TT>;
+  ConvParams p = p0;
+  if (p.RT == 0) p.RT = (p.M - p.m_base + G::BM - 1) / G::BM;
+  p.CT = (p.Cout + KW_BN - 1) / KW_BN;
+  auto kern = conv3d_k3_kw_kernel<TT, RES>;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_conv3d_k3_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT), dim3(GEMM_THREADS), G::LDS, stream, p);
+  LTXK_CHECK_LAUNCH("ltxk_conv3d_k3_bf16(kw)");
+  return LTXK_OK;
+}
+
+// whole rounds of 256-row tiles, then the rows of the short last round as 128-row tiles (same bits: a row's sum does not
+// depend on the tile it is in)
+template <bool RES>
+static int conv_launch_kw_all(const ConvParams& p0, hipStream_t stream) {
+  ConvParams p = p0;
+  const int CT = (p.Cout + KW_BN - 1) / KW_BN;
+  const int RT = (p.M + 255) / 256;
+  const int tiles = RT * CT;
+  const int rem_rt = (tiles % 256) / CT;
+  const int rt_main = RT - rem_rt;
+  const long tail_rows = (long)p.M - (long)rt_main * 256;
+  const long tail_tiles = (tail_rows + 127) / 128 * CT;
+  if (LTXK_AB_INT("LTXK_CONV_TAIL", 1) && tiles > 256 && rem_rt > 0 && rt_main > 0 && (long)rt_main * CT % 256 < CT && tail_tiles <= 256) {
+    p.m_base = 0; p.RT = rt_main;
+    int rc = conv_launch_kw<4, RES>(p, stream);
+    if (rc != LTXK_OK) return rc;
+    p.m_base = rt_main * 256; p.RT = (int)((tail_rows + 127) / 128);
+    return conv_launch_kw<2, RES>(p, stream);
+  }
+  p.m_base = 0; p.RT = RT;
+  return conv_launch_kw<4, RES>(p, stream);
+}
+
 template <int TT, int WN, bool RES>
 static int conv_launch_plain(const ConvParams& p, hipStream_t stream) {
   using G = GemmGeom<TT, WN>;
@@ -508,6 +895,18 @@ extern "C" int ltxk_conv3d_k3_bf16(const ltxk_conv3d_args* a, void* stream) {
   float* ws = a->act_out ? nullptr : (float*)a->workspace;          // the fused row statistic lives in the tile: no split-K
   const size_t wsb = ws ? (size_t)a->workspace_bytes : 0;
   LTXK_CHECK_ARG(((uintptr_t)ws & 15) == 0, "ltxk_conv3d_k3_bf16: workspace must be 16-byte aligned");
+  // kw-reuse form (see conv3d_k3_kw_kernel): the 27-tap convolution on volumes at least 64 voxels wide whose tile grid
+  // fills the chip without split-K
+  {
+    const long tiles_kw = ((M + 255) / 256) * ((a->Cout + KW_BN - 1) / KW_BN);
+    const int kw_mode = LTXK_AB_INT("LTXK_CONV_KW", 1);
+    // (A/B build: 2 = wherever legal, 0 = never.  By default only where one 128-column tile spans Cout: with several
+    // column tiles the A panel is re-fetched per column tile and the per-tap kernel's 160x256 tile moves fewer bytes.)
+    const bool kw_pays = kw_mode == 2 || a->Cout <= KW_BN;
+    if (kw_mode && kw_pays && p.ntaps == 27 && a->W >= 64 && a->Cin % 32 == 0 && !a->act_out && a->out && (tiles_kw > 128 || !ws)) {
+      return res ? conv_launch_kw_all<true>(p, st) : conv_launch_kw_all<false>(p, st);
+    }
+  }
   if (a->Cout <= 128) {       // 256x128 tile: no wasted MFMA columns on the 128-channel stage
     return res ? conv_launch<4, 2, true>(p, st, ws, wsb) : conv_launch<4, 2, false>(p, st, ws, wsb);
   }

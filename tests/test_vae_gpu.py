@@ -356,3 +356,45 @@ def test_resize_area_vs_oracle(dev, shape, out, dt):
         assert float((dm > 0).float().mean()) < 2e-3 and float(dm.max()) <= 2 ** -7
     with pytest.raises(Exception, match="not a downscale"):
         ops.resize_area(x.to(dev), shape[-2] + 1, shape[-1])
+
+
+KW_CASES = [  # (B, D, H, W, Cin, Cout, causal, pad_mode, residual)
+    (1, 3, 128, 128, 128, 128, 0, 1, True),      # the 128-channel stage: tiles = 2 image rows exactly
+    (1, 2, 70, 100, 128, 128, 1, 1, False),      # W not a multiple of 16: runs start inside MFMA row blocks, ragged last tile
+    (1, 3, 64, 64, 256, 256, 0, 1, True),        # the 256-channel stage: W = 64, two column tiles
+    (2, 2, 66, 72, 64, 48, 1, 0, False),         # zero padding (encoder side), two batch items, Cout 48 (conv_out), Cin 64
+    (1, 2, 96, 192, 128, 512, 2, 0, False),      # zero temporal halo (upsampler mode), 4 column tiles
+    (1, 1, 130, 65, 128, 128, 0, 1, True),       # one frame, W = 65
+]
+
+
+@pytest.mark.parametrize("case", KW_CASES)
+def test_conv3d_kw_reuse_kernel_vs_per_tap_kernel(dev, case, monkeypatch):
+    """conv3d_k3_kw_kernel (one A panel per (kd,kh) shared by the three kw taps) against the per-tap kernel (LTXK_CONV_KW=0
+    in the A/B build): the same products and rounding points summed in another K order -> fp32-order differences only
+    (rare single-ulp flips), on every halo mode, widths that do / do not align runs with MFMA blocks, ragged tiles, several
+    column tiles, with and without the residual; the tail launch of half tiles gives the same bits as one launch."""
+    from mlx_video_amd import _lib, video_vae as V
+    B, D, H, W, Cin, Cout, causal, pad, res = case
+    g = torch.Generator(device=dev).manual_seed(B * 7 + H + W + Cin + Cout)
+    x = torch.randn((B, D, H, W, Cin), generator=g, device=dev).to(torch.bfloat16)
+    w = (torch.randn((Cout, 3, 3, 3, Cin), generator=g, device=dev) * 0.02).to(torch.bfloat16)
+    b = (torch.randn(Cout, generator=g, device=dev) * 0.1).to(torch.bfloat16)
+    r = torch.randn((B, D, H, W, Cout), generator=g, device=dev).to(torch.bfloat16) if res else None
+    with _lib.use_library(_lib.AB_LIB_PATH):
+        outs = {}
+        for name, env in (("per_tap", {"LTXK_CONV_KW": "0"}), ("kw", {"LTXK_CONV_KW": "2"}), ("kw_no_tail", {"LTXK_CONV_KW": "2", "LTXK_CONV_TAIL": "0"})):
+            for k in ("LTXK_CONV_KW", "LTXK_CONV_TAIL"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            outs[name] = V.conv3d(x, w, b, causal, pad, resid=r)
+            torch.cuda.synchronize()
+    assert torch.equal(outs["kw"], outs["kw_no_tail"])
+    a, ref = outs["kw"].float(), outs["per_tap"].float()
+    assert bool(torch.isfinite(a).all())
+    parity.auto(rel_l2(a, ref), 3e-4)
+    d = (a - ref).abs()
+    assert float((d > 2.0 ** -7 * torch.maximum(a.abs(), ref.abs()).clamp_min(1e-3)).float().mean()) < 1e-3      # > 1 ulp apart: almost never
+    # the product library takes the kw form where one column tile spans Cout, the per-tap form otherwise
+    assert torch.equal(V.conv3d(x, w, b, causal, pad, resid=r), outs["kw" if Cout <= 128 else "per_tap"])
