@@ -521,9 +521,15 @@ static int pick_tt(int M, int N) {
 // accumulating in place.  Only launches that fill whole rounds use it (big_tile_pays below).  Same bits as the 160x256 kernel.
 namespace ltxk {
 
-constexpr int BIG_BM = 320, BIG_BN = 256;
-constexpr int BIG_STAGE_W = BIG_BN * 128, BIG_STAGE = (BIG_BN + BIG_BM) * 128, BIG_LDS = 2 * BIG_STAGE;
-static_assert(BIG_LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+// RB = 16-row MFMA blocks per wave: 5 -> the 320 x 256 tile (80 x 128 per wave); 4 -> a 256 x 256 tile (64 x 128 per wave) for
+// launches whose row count is a multiple of 256 but not of 320 (the text k|v pair: M = B*1024; round 3).
+constexpr int BIG_BN = 256;
+constexpr int BIG_STAGE_W = BIG_BN * 128;
+template <int RB> struct BigGeom {
+  static constexpr int BM = 64 * RB;
+  static constexpr int STAGE = (BIG_BN + BM) * 128, LDS = 2 * STAGE;
+  static_assert(LDS <= 160 * 1024, "two stages must fit the CU's LDS");
+};
 
 #ifndef LTXK_BIG_PPR
 #define LTXK_BIG_PPR 3   // LDS-DMA pieces issued per MFMA row of sub-step 0
@@ -534,20 +540,21 @@ static_assert(BIG_LDS <= 160 * 1024, "two stages must fit the CU's LDS");
 #define LTXK_MFMA_V(acc, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a))
 
 // TRANS: the tile is written transposed per batch (V^T) - operand roles swapped so that a lane holds 4 consecutive tokens
-template <int EPI, bool TRANS>
+template <int EPI, bool TRANS, int RB>
 __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, int m0, int n0, int wave, int lane) {
-  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves of 80 x 128
+  constexpr int BIG_STAGE = BigGeom<RB>::STAGE;
+  const int wm = wave >> 1, wn = wave & 1;                       // 4 x 2 waves of (16*RB) x 128
 
-  // loader: 32 W pieces + 40 A pieces of 1 KiB (8 rows x 128 B) per stage; wave w owns W pieces 4w..4w+3 and A pieces
-  // 5w..5w+4.  Source = wave-uniform base (SGPR) + per-lane offset; the 16-byte chunk is pre-swizzled by the row.
+  // loader: 32 W pieces + 8*RB A pieces of 1 KiB (8 rows x 128 B) per stage; wave w owns W pieces 4w..4w+3 and A pieces
+  // RB*w..RB*w+RB-1.  Source = wave-uniform base (SGPR) + per-lane offset; the 16-byte chunk is pre-swizzled by the row.
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
   const unsigned w_lane = (unsigned)((lrow * p.K + chunk * 8) * 2);
   const uint64_t w_base = (uint64_t)(p.W + (size_t)(n0 + wave * 32) * p.K);
-  unsigned a_lane[5];
+  unsigned a_lane[RB];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    int r = m0 + (wave * 5 + i) * 8 + lrow;
+  for (int i = 0; i < RB; ++i) {
+    int r = m0 + (wave * RB + i) * 8 + lrow;
     r = r < p.M ? r : p.M - 1;
     a_lane[i] = (unsigned)(((size_t)(r - m0) * p.lda + chunk * 8) * 2);
   }
@@ -556,23 +563,23 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
     char* base = smem + slot * BIG_STAGE;
     const unsigned ko = (unsigned)(kt * GEMM_BK * 2);
     if (i < 4) glds16_s(w_base + (uint64_t)i * 8 * p.K * 2 + ko, w_lane, base + (wave * 4 + i) * 1024);
-    else if (i < 9) glds16_s(a_base + ko, a_lane[i - 4 < 5 ? i - 4 : 0], base + BIG_STAGE_W + (wave * 5 + (i - 4)) * 1024);
+    else if (i < 4 + RB) glds16_s(a_base + ko, a_lane[i - 4 < RB ? i - 4 : 0], base + BIG_STAGE_W + (wave * RB + (i - 4)) * 1024);
   };
 
-  f32x4 acc[5][8];
+  f32x4 acc[RB][8];
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / GEMM_BK;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) issue_piece(i, 0, 0);
+  for (int i = 0; i < 4 + RB; ++i) issue_piece(i, 0, 0);
 
   const int frow = (lane & 15) * 128;
   const int koff0 = ((lane >> 4) ^ (lane & 7)) << 4;
   const int koff1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
-  bf16x8 wf[8], af[5];
+  bf16x8 wf[8], af[RB];
   auto mma = [](f32x4& c, const bf16x8& w, const bf16x8& a) __attribute__((always_inline)) {
     if constexpr (TRANS) LTXK_MFMA_V(c, a, w);
     else LTXK_MFMA_V(c, w, a);
@@ -586,7 +593,7 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
 #pragma unroll
     for (int q = 0; q < 8; ++q) wf[j][q] = (bf16)0.f;
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int q = 0; q < 8; ++q) af[i][q] = (bf16)0.f;
   auto kstep = [&](int kt, auto last_c) __attribute__((always_inline)) {
@@ -595,7 +602,7 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int slot = kt & 1;
     const char* wb = smem + slot * BIG_STAGE + (wn * 128) * 128 + frow;
-    const char* ab = smem + slot * BIG_STAGE + BIG_STAGE_W + (wm * 80) * 128 + frow;
+    const char* ab = smem + slot * BIG_STAGE + BIG_STAGE_W + (wm * 16 * RB) * 128 + frow;
     const int kt1 = kt + 1;
     // K-sub-step 0 fragments.  The W fragments whose registers are free first, then the held-back columns, each of their
     // last MFMAs freeing one A fragment register for the new stage, then the remaining W fragments.
@@ -605,7 +612,7 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < RB; ++i) {
 #pragma unroll
       for (int j = 8 - HB; j < 8; ++j) mma(acc[i][j], wf[j], af[i]);
       af[i] = *(const bf16x8*)(ab + i * 2048 + koff0);
@@ -617,16 +624,16 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < RB; ++i) {
 #pragma unroll
         for (int j = 0; j < (ks == 0 ? 8 : 8 - HB); ++j) {
           mma(acc[i][j], wf[j], af[i]);
           // the last row of sub-step 0 frees the W fragments one by one: refill each for sub-step 1 at once
-          if (ks == 0 && i == 4) wf[j] = *(const bf16x8*)(wb + j * 2048 + koff1);
+          if (ks == 0 && i == RB - 1) wf[j] = *(const bf16x8*)(wb + j * 2048 + koff1);
         }
         if (ks == 0) {
           af[i] = *(const bf16x8*)(ab + i * 2048 + koff1);        // row i done: its A fragment register is free
-          // next stage's LDS-DMA: all nine pieces in the first three MFMA rows, so they have most of a K-step to land
+          // next stage's LDS-DMA: all 4 + RB pieces in the first three MFMA rows, so they have most of a K-step to land
           if constexpr (!LAST) {
 #pragma unroll
             for (int q = 0; q < LTXK_BIG_PPR; ++q) issue_piece(i * LTXK_BIG_PPR + q, kt1, slot ^ 1);   // (no-op past piece 8)
@@ -639,15 +646,16 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
   for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, IntC<0>{});
   kstep(nk - 1, IntC<1>{});
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
     for (int j = 8 - HB; j < 8; ++j) mma(acc[i][j], wf[j], af[i]);
   // hipcc does not see the asm MFMAs as matrix instructions and pads no hazard: let the last ones retire before the
   // accumulators are read (the operands tie the wait to the registers written last)
+  constexpr int L1 = RB - 1, L2 = RB - 2, L3 = RB - 3;
   asm volatile("s_nop 15\n\ts_nop 15"
-               : "+v"(acc[3][4]), "+v"(acc[3][5]), "+v"(acc[3][6]), "+v"(acc[3][7]), "+v"(acc[4][0]), "+v"(acc[4][1]),
-                 "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[4][4]), "+v"(acc[4][5]), "+v"(acc[4][6]), "+v"(acc[4][7]),
-                 "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[2][7]), "+v"(acc[0][6]), "+v"(acc[1][6]), "+v"(acc[2][6]), "+v"(acc[0][5]), "+v"(acc[1][5]), "+v"(acc[2][5]));
+               : "+v"(acc[L2][4]), "+v"(acc[L2][5]), "+v"(acc[L2][6]), "+v"(acc[L2][7]), "+v"(acc[L1][0]), "+v"(acc[L1][1]),
+                 "+v"(acc[L1][2]), "+v"(acc[L1][3]), "+v"(acc[L1][4]), "+v"(acc[L1][5]), "+v"(acc[L1][6]), "+v"(acc[L1][7]),
+                 "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[L3][7]), "+v"(acc[0][6]), "+v"(acc[1][6]), "+v"(acc[L3][6]), "+v"(acc[0][5]), "+v"(acc[1][5]), "+v"(acc[L3][5]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if constexpr (!TRANS) {
@@ -661,8 +669,8 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
       bpre[j] = p.bias ? *(const bf16x4*)(p.bias + n) : bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int m = m0 + wm * 80 + i * 16 + (lane & 15);
+    for (int i = 0; i < RB; ++i) {
+      const int m = m0 + wm * 16 * RB + i * 16 + (lane & 15);
       float ss[2] = {0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -716,8 +724,8 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
       const int n = n0 + wn * 128 + j * 16 + (lane & 15);
       const float b = p.bias ? (float)p.bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const int m = m0 + wm * 80 + i * 16 + tq;
+      for (int i = 0; i < RB; ++i) {
+        const int m = m0 + wm * 16 * RB + i * 16 + tq;
         if (m >= p.M) continue;
         bf16x4 o;
 #pragma unroll
@@ -742,27 +750,28 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
 }
 
 // MODE as in gemm_bf16_kernel: 0 row-major with EPI, 1 transposed, 2 split at n_split
-template <int EPI, int MODE>
+template <int EPI, int MODE, int RB>
 __global__ __launch_bounds__(512) void gemm_bf16_big_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int rt, ct;
   map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
-  const int m0 = rt * BIG_BM, n0 = ct * BIG_BN;
+  const int m0 = rt * BigGeom<RB>::BM, n0 = ct * BIG_BN;
   if constexpr (MODE == 0) {
-    gemm_big_tile<EPI, false>(p, smem, m0, n0, wave, lane);
+    gemm_big_tile<EPI, false, RB>(p, smem, m0, n0, wave, lane);
   } else if constexpr (MODE == 1) {
-    gemm_big_tile<LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+    gemm_big_tile<LTXK_EPI_BIAS, true, RB>(p, smem, m0, n0, wave, lane);
   } else {
-    if (n0 < p.n_split) gemm_big_tile<EPI, false>(p, smem, m0, n0, wave, lane);
-    else gemm_big_tile<LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+    if (n0 < p.n_split) gemm_big_tile<EPI, false, RB>(p, smem, m0, n0, wave, lane);
+    else gemm_big_tile<LTXK_EPI_BIAS, true, RB>(p, smem, m0, n0, wave, lane);
   }
 }
 
-template <int EPI, int MODE>
-static int launch_big(const GemmParams& p, hipStream_t stream) {
-  auto kern = gemm_bf16_big_kernel<EPI, MODE>;
+template <int EPI, int MODE, int RB>
+static int launch_big_rb(const GemmParams& p, hipStream_t stream) {
+  constexpr int BIG_LDS = BigGeom<RB>::LDS;
+  auto kern = gemm_bf16_big_kernel<EPI, MODE, RB>;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -779,6 +788,11 @@ static int launch_big(const GemmParams& p, hipStream_t stream) {
   return LTXK_OK;
 }
 
+template <int EPI, int MODE>
+static int launch_big(const GemmParams& p, hipStream_t stream, int rb) {
+  return rb == 4 ? launch_big_rb<EPI, MODE, 4>(p, stream) : launch_big_rb<EPI, MODE, 5>(p, stream);
+}
+
 // (FF2 - N=4096, K=16384: 128 big tiles - was also tried on this tile as split-K pairs, two workgroups per tile with one K
 // half each, the first to finish parking its fp32 partial tile in a workspace, the second adding it and running the
 // gate + residual epilogue: 416 us against 302 us with agent-scope release / acquire fences around the hand-over (each is
@@ -786,11 +800,22 @@ static int launch_big(const GemmParams& p, hipStream_t stream) {
 // K=4096 116 against 90 us.  The meeting costs more than the bigger tile saves.  Removed.)
 // The big tile pays when it still fills whole 256-CU rounds: rounds x 2 (tile area) x 0.9 (measured gain) against the
 // 160-row rounds.  M=2560: N=16384 -> 2 rounds against 4 (taken); N=12288 -> 2 against 3, N=4096 -> 1 against 1 (not).
-static bool big_tile_pays(int M, int N) {
+// Returns the rows-per-wave block count of the big tile to use (5: 320 x 256, 4: 256 x 256) or 0 for the 160-row tiles:
+// cost = rounds of 256 CUs x tile rows x per-row factor (1.0 for the 160-row tile, 0.9 measured for the 320-row tile, 0.93 for
+// the 256-row one, whose 64 x 128 wave tile reads 0.375 fragments per MFMA against 0.325).  M=2560: N=16384 -> 320 (2 rounds
+// against 4), N=8192 -> 320 (1 against 2), N=4096 -> 160 (1 against 1); M=2048 (text k|v), N=8192 -> 256 (exactly one round of
+// 8 x 32 tiles; the 320-row tile leaves 32 CUs idle and a 128-row remainder tile).
+static int big_tile_choice(int M, int N) {
   const long CT = N / BIG_BN;
-  const long rounds_b = (((M + BIG_BM - 1) / BIG_BM) * CT + 255) / 256;
-  const long rounds_s = (((M + 159) / 160) * CT + 255) / 256;
-  return rounds_b * 18 < rounds_s * 10;
+  auto tiles = [&](int bm) { return ((long)(M + bm - 1) / bm) * CT; };
+  auto rounds = [&](int bm) { return (tiles(bm) + 255) / 256; };
+  const long cost_s = rounds(160) * 160 * 100, cost_5 = rounds(320) * 320 * 90, cost_4 = rounds(256) * 256 * 93;
+  // the 256-row tile only where it fills whole rounds with whole tiles (M=6656, N=16384: 6.5 rounds of it measured 763 us
+  // against 728 us for 5.25 rounds of the 320-row tile - a part-filled round costs less than a whole one, and the model
+  // above cannot tell by how much; profiles/r03_gemm_256tile_ab.log)
+  if (M % 256 == 0 && tiles(256) % 256 == 0 && cost_4 < cost_s && cost_4 < cost_5) return 4;
+  if (cost_5 < cost_s) return 5;
+  return 0;
 }
 
 }  // namespace ltxk
@@ -849,19 +874,21 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   p.RT = (a->M + bm - 1) / bm;
   p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
   hipStream_t st = (hipStream_t)stream;
-  // 0: off, 2: whenever legal (A/B build only: tests compare both tiles bit for bit)
   const int big_env = LTXK_AB_INT("LTXK_GEMM_BIG", 1);
   const bool big_legal = a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
                          (a->epilogue == LTXK_EPI_BIAS || ((a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU) && !a->sumsq));
-  if (big_legal && tt_env == 0 && (big_env == 2 || (big_env == 1 && big_tile_pays(a->M, a->N)))) {
-    p.RT = (a->M + BIG_BM - 1) / BIG_BM;
+  // A/B build: LTXK_GEMM_BIG=0 never, 2 / 3 the 320-row / 256-row tile whenever legal (tests compare the tiles bit for bit)
+  const int rb = !big_legal || tt_env != 0 || big_env == 0 ? 0 : (big_env == 2 ? 5 : (big_env == 3 ? 4 : big_tile_choice(a->M, a->N)));
+  if (rb) {
+    const int bm = 64 * rb;
+    p.RT = (a->M + bm - 1) / bm;
     p.CT = a->N / BIG_BN;
-    if (split) return launch_big<LTXK_EPI_BIAS, 2>(p, st);
-    if (trans) return launch_big<LTXK_EPI_BIAS, 1>(p, st);
+    if (split) return launch_big<LTXK_EPI_BIAS, 2>(p, st, rb);
+    if (trans) return launch_big<LTXK_EPI_BIAS, 1>(p, st, rb);
     switch (a->epilogue) {
-      case LTXK_EPI_BIAS: return launch_big<LTXK_EPI_BIAS, 0>(p, st);
-      case LTXK_EPI_BIAS_GELU: return launch_big<LTXK_EPI_BIAS_GELU, 0>(p, st);
-      default: return launch_big<LTXK_EPI_BIAS_SILU, 0>(p, st);
+      case LTXK_EPI_BIAS: return launch_big<LTXK_EPI_BIAS, 0>(p, st, rb);
+      case LTXK_EPI_BIAS_GELU: return launch_big<LTXK_EPI_BIAS_GELU, 0>(p, st, rb);
+      default: return launch_big<LTXK_EPI_BIAS_SILU, 0>(p, st, rb);
     }
   }
   // (A persistent form for the multi-round launches - one workgroup per CU walking tiles b, b+256, ..., the LDS-DMA

@@ -36,10 +36,44 @@ def image_to_conditioning(image: np.ndarray) -> torch.Tensor:
     return t * 2.0 - 1.0
 
 
+VIDEO_SUFFIXES = (".mp4", ".mov", ".mkv", ".webm", ".avi", ".m4v", ".gif")
+
+
+def decode_video_ffmpeg(path: Union[str, Path], frame_cap: Optional[int] = None) -> np.ndarray:
+    """Decode a video FILE to (F,H,W,3) uint8 RGB frames through an ffmpeg child process (the reference decodes with
+    cv2.VideoCapture, utils.py:587-606; neither cv2 nor PyAV exists in this image, and output already leaves through an
+    ffmpeg pipe, generate.py:1833-1893): ffprobe gives the frame size, ffmpeg streams rawvideo rgb24 on stdout.
+    FileNotFoundError when the binaries are not installed, ValueError when nothing decodes (utils.py:588-589,608-609)."""
+    import json
+    import shutil
+    import subprocess
+    ffmpeg, ffprobe = shutil.which("ffmpeg"), shutil.which("ffprobe")
+    if ffmpeg is None or ffprobe is None:
+        raise FileNotFoundError("ffmpeg / ffprobe not found: video files cannot be decoded here; pass a directory of frames, "
+                                "an .npy array of (F,H,W,3) frames or a pixel tensor instead")
+    pr = subprocess.run([ffprobe, "-v", "error", "-select_streams", "v:0", "-show_entries", "stream=width,height", "-of", "json",
+                         str(path)], capture_output=True, text=True)
+    try:
+        st = json.loads(pr.stdout)["streams"][0]
+        w, h = int(st["width"]), int(st["height"])
+    except (ValueError, KeyError, IndexError):
+        raise ValueError(f"Unable to open video: {path}")
+    cmd = [ffmpeg, "-v", "error", "-i", str(path)] + (["-frames:v", str(int(frame_cap))] if frame_cap else []) + \
+          ["-f", "rawvideo", "-pix_fmt", "rgb24", "-"]
+    out = subprocess.run(cmd, capture_output=True)
+    n = len(out.stdout) // (w * h * 3)
+    if out.returncode != 0 or n == 0:
+        raise ValueError(f"No frames decoded from video: {path}")
+    return np.frombuffer(out.stdout[: n * w * h * 3], dtype=np.uint8).reshape(n, h, w, 3)
+
+
 def load_frames(source: Union[str, Path, np.ndarray], height: int, width: int, frame_cap: Optional[int] = None) -> np.ndarray:
-    """Frame sequence for video conditioning (stand-in for utils.py:578-613, which decodes with cv2):
-    a directory of images (sorted) or an (F,H,W,3) uint8/float array or .npy file.  (F,H,W,3) in [0,1]."""
+    """Frame sequence for video conditioning (utils.py:578-613, which decodes with cv2 and resizes every decoded uint8
+    frame with INTER_AREA): a video file (through ffmpeg, where installed), a directory of images (sorted), or an
+    (F,H,W,3) uint8/float array or .npy file.  (F,H,W,3) in [0,1]."""
     from PIL import Image
+    if isinstance(source, (str, Path)) and Path(source).is_file() and Path(source).suffix.lower() in VIDEO_SUFFIXES:
+        source = decode_video_ffmpeg(source, frame_cap)
     if isinstance(source, (str, Path)) and Path(source).is_dir():
         files = sorted(p for p in Path(source).iterdir() if p.suffix.lower() in (".png", ".jpg", ".jpeg", ".bmp"))
         if not files:

@@ -62,7 +62,7 @@ def test_gemm_epilogues_deterministic(dev, M, N, K):
     parity.auto(worst, 6e-3)
 
 
-BIG_SHAPES = [(320, 256, 64), (2560, 1024, 256), (700, 512, 192), (2560, 4096, 1024), (1296, 768, 448)]
+BIG_SHAPES = [(320, 256, 64), (2560, 1024, 256), (700, 512, 192), (2560, 4096, 1024), (1296, 768, 448), (2048, 2048, 512)]
 
 
 @pytest.mark.parametrize("M,N,K", BIG_SHAPES)
@@ -78,14 +78,15 @@ def test_gemm_320x256_tile_equals_160x256_tile(dev, M, N, K, monkeypatch, ab_lib
     for epi in (0, 1, 2):
         for bias in (b, None):
             outs = {}
-            for mode in ("0", "2"):
+            for mode in ("0", "2", "3"):                     # 160-row tiles, the 320 x 256 tile, the 256 x 256 tile
                 monkeypatch.setenv("LTXK_GEMM_BIG", mode)
                 buf = torch.full((M + 1, N + 64), 7.0, device=dev, dtype=BF)
                 ops.gemm(a, w, bias, out=buf[:M, :N], epilogue=epi)
                 torch.cuda.synchronize()
                 assert torch.all(buf[M:] == 7.0) and torch.all(buf[:, N:] == 7.0), "wrote outside the output view"
                 outs[mode] = buf[:M, :N].clone()
-            assert torch.equal(outs["0"], outs["2"]), f"epilogue {epi} bias={bias is not None}"
+            assert torch.equal(outs["0"], outs["2"]), f"320-row tile: epilogue {epi} bias={bias is not None}"
+            assert torch.equal(outs["0"], outs["3"]), f"256-row tile: epilogue {epi} bias={bias is not None}"
     monkeypatch.setenv("LTXK_GEMM_BIG", "2")
     acc = a.float() @ w.float().t()
     ref = torch.nn.functional.gelu((acc + b.float()).to(BF).float(), approximate="tanh")
@@ -121,7 +122,7 @@ def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monk
     T = M // 2
     ld = (T + 63) // 64 * 64
     res = {}
-    for mode in ("0", "2"):
+    for mode in ("0", "2", "3"):
         monkeypatch.setenv("LTXK_GEMM_BIG", mode)
         ss = torch.full((M, N // 64 + 1), -1.0, device=dev, dtype=torch.float32)
         y = ops.gemm(a, w, b, sumsq=ss)
@@ -134,8 +135,9 @@ def test_gemm_320x256_tile_sumsq_transposed_and_split_outputs(dev, M, N, K, monk
         ops.gemm(a, w, b, out=k2, out2=v2, n_split=ns, out_tokens_per_batch=T, sumsq=ss2)
         torch.cuda.synchronize()
         res[mode] = (y, ss, vt, k2, v2, ss2)
-    for name, x0, x2 in zip(("y", "sumsq", "vt", "split.k", "split.vt", "split.sumsq"), res["0"], res["2"]):
-        assert torch.equal(x0, x2), name
+    for name, x0, x2, x3 in zip(("y", "sumsq", "vt", "split.k", "split.vt", "split.sumsq"), res["0"], res["2"], res["3"]):
+        assert torch.equal(x0, x2), name + " (320-row tile)"
+        assert torch.equal(x0, x3), name + " (256-row tile)"
     y, ss, vt, k2, v2, ss2 = res["2"]
     assert torch.all(ss[:, -1] == -1.0) and torch.all(vt[:, :, T:] == 3.0)
     assert torch.equal(vt[:, :, :T], y.reshape(2, T, N).transpose(1, 2))

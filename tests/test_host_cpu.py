@@ -384,3 +384,36 @@ def test_cli_heuristics_table():
     assert run(["--pipeline", "dev"], {"LTX_EVAL_INTERVAL": "7"}).eval_interval == 7
     assert run(["--pipeline", "dev", "--eval-interval", "0"]).eval_interval == 1
     assert run(["--pipeline", "dev", "--eval-interval", "3"], {"LTX_EVAL_INTERVAL": "7"}).eval_interval == 3
+
+
+def test_video_file_decode_through_ffmpeg(tmp_path, monkeypatch):
+    """utils.py:578-613: video FILE conditioning.  No decoder library exists in this image; media.decode_video_ffmpeg drives
+    ffprobe + ffmpeg child processes.  Stand-in binaries prove the protocol (size from ffprobe's JSON, raw rgb24 frames from
+    ffmpeg's stdout, frame_cap as -frames:v) and the reference's error behaviour."""
+    import shutil, stat
+    import numpy as np
+    from mlx_video_amd import media
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    with pytest.raises(FileNotFoundError, match="ffmpeg"):
+        media.decode_video_ffmpeg(tmp_path / "v.mp4")
+    frames = np.random.default_rng(1).integers(0, 255, (5, 6, 8, 3), dtype=np.uint8)
+    (tmp_path / "raw.bin").write_bytes(frames.tobytes())
+    probe = tmp_path / "ffprobe"
+    probe.write_text('#!/bin/sh\necho \'{"streams": [{"width": 8, "height": 6}]}\'\n')
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(f'#!/bin/sh\nn=5\nprev=""\nfor a in "$@"; do if [ "$prev" = "-frames:v" ]; then n=$a; fi; prev=$a; done\n'
+                  f'head -c $((n*6*8*3)) {tmp_path}/raw.bin\n')
+    for f in (probe, ff):
+        f.chmod(f.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setattr(shutil, "which", lambda name: str(tmp_path / name))
+    vid = tmp_path / "v.mp4"
+    vid.write_bytes(b"x")
+    got = media.decode_video_ffmpeg(vid)
+    assert got.shape == (5, 6, 8, 3) and np.array_equal(got, frames)
+    assert np.array_equal(media.decode_video_ffmpeg(vid, frame_cap=3), frames[:3])
+    fr = media.load_frames(vid, 6, 8, frame_cap=4)                      # the path generate._cond_pixels takes for --video-conditioning FILE
+    assert fr.shape == (4, 6, 8, 3) and np.allclose(fr, frames[:4].astype(np.float32) / 255.0)
+    assert media.load_frames(vid, 3, 4).shape == (5, 3, 4, 3)           # area-filter resize of the decoded uint8 frames
+    probe.write_text("#!/bin/sh\necho '{}'\n")
+    with pytest.raises(ValueError, match="Unable to open video"):
+        media.decode_video_ffmpeg(vid)
