@@ -358,13 +358,14 @@ def test_resize_area_vs_oracle(dev, shape, out, dt):
         ops.resize_area(x.to(dev), shape[-2] + 1, shape[-1])
 
 
-KW_CASES = [  # (B, D, H, W, Cin, Cout, causal, pad_mode, residual)
+KW_CASES = [  # (B, D, H, W, Cin, Cout, causal, pad_mode, residual); every case has > 128 tiles of 256 x 128, so the kw form runs
     (1, 3, 128, 128, 128, 128, 0, 1, True),      # the 128-channel stage: tiles = 2 image rows exactly
-    (1, 2, 70, 100, 128, 128, 1, 1, False),      # W not a multiple of 16: runs start inside MFMA row blocks, ragged last tile
-    (1, 3, 64, 64, 256, 256, 0, 1, True),        # the 256-channel stage: W = 64, two column tiles
-    (2, 2, 66, 72, 64, 48, 1, 0, False),         # zero padding (encoder side), two batch items, Cout 48 (conv_out), Cin 64
+    (1, 4, 90, 100, 128, 128, 1, 1, False),      # W not a multiple of 16: runs start inside MFMA row blocks; ragged last tile
+    (1, 5, 64, 64, 256, 256, 0, 1, True),        # the 256-channel stage: W = 64 (5 image rows per tile), two column tiles
+    (2, 4, 66, 72, 64, 48, 1, 0, False),         # zero padding (encoder side), two batch items, Cout 48 (conv_out), Cin 64
     (1, 2, 96, 192, 128, 512, 2, 0, False),      # zero temporal halo (upsampler mode), 4 column tiles
-    (1, 1, 130, 65, 128, 128, 0, 1, True),       # one frame, W = 65
+    (1, 2, 260, 65, 128, 128, 0, 1, True),       # W = 65: odd width, two frames
+    (1, 3, 100, 131, 192, 128, 2, 1, True),      # Cin = 192 (six 32-channel blocks), W = 131, zero temporal halo + reflect
 ]
 
 
@@ -391,6 +392,7 @@ def test_conv3d_kw_reuse_kernel_vs_per_tap_kernel(dev, case, monkeypatch):
             outs[name] = V.conv3d(x, w, b, causal, pad, resid=r)
             torch.cuda.synchronize()
     assert torch.equal(outs["kw"], outs["kw_no_tail"])
+    assert not torch.equal(outs["kw"], outs["per_tap"]) or Cin <= 64, "the kw form did not run (same bits as the per-tap kernel)"
     a, ref = outs["kw"].float(), outs["per_tap"].float()
     assert bool(torch.isfinite(a).all())
     parity.auto(rel_l2(a, ref), 3e-4)
