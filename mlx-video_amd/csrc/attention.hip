@@ -27,7 +27,7 @@ constexpr int FA_K_BYTES = FA_BK * FA_DH * 2;    // 16 KiB: [64 keys][256 B]
 constexpr int FA_V_BYTES = FA_DH * FA_BK * 2;    // 16 KiB: [128 d][128 B]
 constexpr int FA_STAGE = FA_K_BYTES + FA_V_BYTES;
 constexpr int FA_LDS = 2 * FA_STAGE;
-constexpr int FA_DEFAULT_MFMA = 32;   // MFMA shape of the shipped kernel: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (fa_body16)
+constexpr int FA_DEFAULT_MFMA = 16;   // MFMA shape of the shipped kernel: 32 = v_mfma_f32_32x32x16_bf16, 16 = v_mfma_f32_16x16x32_bf16 (fa_body16)
 
 struct FaParams {
   const bf16* q; const bf16* k; const bf16* vt; bf16* out;
@@ -284,7 +284,6 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
     for (int kbi = 0; kbi < NKB; ++kbi)
 #pragma unroll
       for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kbi][j]);
-    mx = lane_xor32_max(mx);
     // Deferred rescale: the running max is only raised (and O, l rescaled: 65 VALU ops per lane) when some
     // row's max grew by more than 2^FA_DEFER in the exponent domain; otherwise P is taken against the old
     // max and stays <= 2^FA_DEFER (bf16 keeps its relative precision, l accumulates in fp32).  All of this
@@ -295,9 +294,12 @@ __device__ __forceinline__ void fa_body(const FaParams& p, char* smem, int bh, i
     // on which tile's running max it was taken against, alpha below is an exact power of two, and the whole kernel
     // differs from  O = (bf16(P) @ V) / sum(P),  P = exp2(fma(S, c, -M))  by fp32 summation order only - whatever the
     // tile size, the deferral or the key split of the tail workgroups (oracle/dit.py::sdpa, "flash" policy).
-    const float mxc = mx * p.c;
-    if (__any(mxc - mc_run > FA_DEFER)) {
+    // The deferral test needs no cross-lane exchange: "some row's max grew past the threshold" is the same predicate whether
+    // each lane tests its own half of the keys or the row's full max (the row max is the larger of its two halves, mc_run
+    // is the same in both) - the exchange with lane ^ 32 happens only inside the (rare) rescale.
+    if (__any(mx * p.c - mc_run > FA_DEFER)) {
       asm volatile("" ::: "memory");       // keeps this a real branch: hipcc otherwise if-converts it into 64 multiplies + selects per tile
+      const float mxc = lane_xor32_max(mx) * p.c;
       const float m_new = fmaxf(mc_run, __builtin_ceilf(mxc));
       const float alpha = __builtin_amdgcn_exp2f(mc_run - m_new);
       mc_run = m_new;
@@ -629,16 +631,14 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
 #pragma unroll
       for (int i = 0; i < 2 * NKC; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) mx = vmax(mx, s[i][qb][j]);
-      mx = lane_xor16_max(mx);
-      mx = lane_xor32_max(mx);
-      mxc[qb] = mx * p.c;
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[i][qb][j]);
+      mxc[qb] = mx * p.c;                                   // this lane's keys only: enough for the deferral test (see fa_body)
     }
     if (__any(mxc[0] - mc_run[0] > FA_DEFER || mxc[1] - mc_run[1] > FA_DEFER)) {
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        const float m_new = fmaxf(mc_run[qb], __builtin_ceilf(mxc[qb]));
+        const float m_new = fmaxf(mc_run[qb], __builtin_ceilf(lane_xor32_max(lane_xor16_max(mxc[qb]))));
         const float alpha = __builtin_amdgcn_exp2f(mc_run[qb] - m_new);
         mc_run[qb] = m_new;
         l_run[qb] *= alpha;

@@ -3,6 +3,7 @@
 # only names the output directory - build variants are selected with LTXK_LIB=<other build of libltxk>)
 out=$1; tq=$2; tk=$3; shift 3
 export TMPDIR=/tmp
+mkdir -p $out
 [ $# -eq 0 ] && set -- base
 for v in "$@"; do
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/v${v}_a -- python scripts/prof_attn_rand.py $tq $tk 6 > $out/v${v}_a.log 2>&1

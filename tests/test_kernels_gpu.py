@@ -376,3 +376,28 @@ def test_attention_with_fused_query_prep(dev, rope, H):
         xq = O.apply_split_rotary_emb(xq, cos.expand(B, -1, -1, -1), sin.expand(B, -1, -1, -1), p)
     ref = O.sdpa(xq, k.float().reshape(B, Tk, D), v.float(), H, p)
     parity.auto(rel_l2(fused.reshape(B, T, D), ref), 1e-2)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 32, 1280, 1280), (1, 4, 200, 333), (2, 8, 1280, 1024)])
+def test_flash_attn_mfma_shapes_agree(dev, B, H, Tq, Tk, monkeypatch, ab_lib):
+    """The shipped kernel computes on v_mfma_f32_16x16x32_bf16 (fa_body16); the 32x32x16 form it replaced stays in the A/B
+    build (LTXK_FA_MFMA=32).  Same rounding points (integer softmax offset, P rounded to bf16, l in fp32), another operand
+    map and summation order: fp32-order differences only, with and without the fused query preparation and the tail split."""
+    ops = _ops()
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(B + H + Tq + Tk)
+    q = torch.randn((B * Tq, D), generator=g, device=dev).to(BF)
+    k = torch.randn((B * Tk, D), generator=g, device=dev).to(BF)
+    vt = torch.randn((B, D, (Tk + 63) // 64 * 64), generator=g, device=dev).to(BF)
+    ss = (q.float() ** 2).reshape(B * Tq, D // 64, 64).sum(-1).contiguous()
+    w = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(BF)
+    outs = {}
+    for shape in ("16", "32"):
+        monkeypatch.setenv("LTXK_FA_MFMA", shape)
+        for name, kw in (("plain", {}), ("no_split", dict(tail_split=False)), ("qprep", dict(q_sumsq=ss, q_norm_weight=w, eps=1e-6))):
+            o = torch.empty((B * Tq, D), dtype=BF, device=dev)
+            ops.flash_attn(q, k, vt, o, B, H, Tq, Tk, 1.0 / math.sqrt(128), **kw)
+            outs[(shape, name)] = o
+    torch.cuda.synchronize()
+    for name in ("plain", "no_split", "qprep"):
+        parity.auto(rel_l2(outs[("16", name)], outs[("32", name)]), 3e-4, tag=name)
