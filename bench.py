@@ -80,6 +80,8 @@ def cpu_baseline_block(threads: int):
     for _ in range(REPS):
         x = O.transformer_block(x, ts, ctx, (cos, sin), W, 0, cfg, O.F32)
     dt = (time.perf_counter() - t0) / REPS
+    # "port": this repository's own torch-CPU fp32 restatement of the reference step (oracle/), NOT the reference's MLX-CPU
+    # path - MLX is not installable here
     return {"value": 1.0 / (dt * 48), "unit": "steps/s", "cores": threads, "kind": "port",
             "sample": f"{REPS} of 48 DiT blocks (oracle fp32, B=2 CFG pair, N=1280, S=1024, D=4096) = {dt * REPS:.1f} s, scaled x48/{REPS}"}
 
@@ -358,18 +360,22 @@ def main() -> None:
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
         traffic = None
         try:   # L2->fabric bytes of the dominant GEMM launch (FF1) from separate --pmc passes (gfx950-corrected);
-            # quoted only while the kernel sources still hash to what the passes were measured on
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            if pm.get("source_sha") == source_sha():
+            # quoted only while the kernel sources still hash to what the passes were measured on (newest round first)
+            import glob
+            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                pm = json.load(open(pf))
+                if pm.get("source_sha") != source_sha():
+                    continue
                 k = next(v for n, v in pm["kernels"].items() if "FF1" in n)
                 traffic = {"bytes_per_launch": k["read_bytes_corrected"] + k["write_bytes"], "algorithmic_bytes": k["algorithmic_bytes"],
                            "kernel": "FF1 GEMM M=2560 N=16384 K=4096", "source_sha": pm["source_sha"],
-                           "source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
+                           "source": f"profiles/{os.path.basename(pf)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
                            # same passes: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock held, per launch shape
                            "mfma_busy_frac_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["mfma_busy_frac_of_simd_cycles"], 3)
                                                        for n, v in pm["kernels"].items() if "mfma_busy_frac_of_simd_cycles" in v},
                            "clock_GHz_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["clock_GHz_profiled"], 2)
                                                   for n, v in pm["kernels"].items() if v.get("clock_GHz_profiled")}}
+                break
         except Exception:
             pass
         rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel + gemm_bf16_big_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
@@ -386,7 +392,7 @@ def main() -> None:
     if "flash_attn" in fams:
         fa = fams["flash_attn"]
         ach = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
-        rooflines["flash_attn"] = {"kernel": "ltxk::flash_attn_kernel (4*B*H*Tq*Tk*128 FLOP per launch)", "bound": "mfma", "achieved": ach,
+        rooflines["flash_attn"] = {"kernel": "ltxk::flash_attn16_kernel (4*B*H*Tq*Tk*128 FLOP per launch)", "bound": "mfma", "achieved": ach,
                                    "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
                                    "launches": fa["launches"], "avg_ms": fa["ms"] / fa["launches"]}
         result["attention_tflops"] = ach
@@ -419,7 +425,7 @@ def main() -> None:
             result.update(vres)
             if "vae_conv3d_tflops" in vres:
                 result["roofline_by_family"]["conv3d_k3"] = {
-                    "kernel": "ltxk::conv3d_k3_kernel (2*27*Cin*Cout*voxels FLOP per launch)", "bound": "mfma",
+                    "kernel": "ltxk::conv3d_k3_kw_kernel + conv3d_k3_kernel (2*27*Cin*Cout*voxels FLOP per launch)", "bound": "mfma",
                     "achieved": vres["vae_conv3d_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                     "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None}
         except ImportError:
