@@ -142,8 +142,12 @@ def self_launch(n: int) -> int:
         p.wait()
         rc = rc or p.returncode
     if rc == 0:
-        sys.stdout.write(out0)
-        sys.stdout.flush()
+        # rank 0's result line only (a rehearsal over gloo also prints connection chatter on stdout)
+        lines = [ln for ln in out0.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if not lines:
+            print("[bench] rank 0 printed no result line", file=sys.stderr)
+            return 3
+        print(lines[-1], flush=True)
     else:
         print(f"[bench] a rank failed (exit code {rc}); no result line", file=sys.stderr)
     return rc
