@@ -119,8 +119,40 @@ __device__ __forceinline__ float lane_xor16_max(float x) { float a, b; lane_xor1
 __device__ __forceinline__ float lane_xor32_sum(float x) { float a, b; lane_xor32_pair(x, a, b); return a + b; }
 __device__ __forceinline__ float lane_xor16_sum(float x) { float a, b; lane_xor16_pair(x, a, b); return a + b; }
 
+// v + (v of lane ^ OFF) without an LDS round trip: OFF = 32 / 16 by v_permlane32/16_swap, OFF = 8, 4, 2, 1 by a DPP row rotate
+// (row_ror:OFF adds the lane OFF places up in its row of 16; once the value is symmetric under the larger offsets - as it is
+// in a butterfly that runs 32, 16, 8, 4, 2, 1 - that lane holds the same number as lane ^ OFF).  Same operands, same single add
+// as `v += __shfl_xor(v, OFF, 64)`, which hipcc lowers to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): bit-identical results.
+template <int OFF>
+__device__ __forceinline__ float lane_butterfly_add(float v) {
+  if constexpr (OFF == 32) return lane_xor32_sum(v);
+  else if constexpr (OFF == 16) return lane_xor16_sum(v);
+  else {
+    static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "butterfly offsets are powers of two up to 32");
+    const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + OFF, 0xf, 0xf, false);      // row_ror:OFF
+    return v + __int_as_float(r);
+  }
+}
+
+// Sum over the wave, the same value (bit for bit) in every lane: butterfly 32, 16, 8, 4, 2, 1.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = lane_butterfly_add<32>(v);
+  v = lane_butterfly_add<16>(v);
+  v = lane_butterfly_add<8>(v);
+  v = lane_butterfly_add<4>(v);
+  v = lane_butterfly_add<2>(v);
+  v = lane_butterfly_add<1>(v);
+  return v;
+}
+
+// Sum over aligned groups of LPR lanes (LPR = 16, 32 or 64), butterfly from LPR/2 down.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+  if constexpr (LPR >= 64) v = lane_butterfly_add<32>(v);
+  if constexpr (LPR >= 32) v = lane_butterfly_add<16>(v);
+  if constexpr (LPR >= 16) v = lane_butterfly_add<8>(v);
+  if constexpr (LPR >= 8) v = lane_butterfly_add<4>(v);
+  if constexpr (LPR >= 4) v = lane_butterfly_add<2>(v);
+  if constexpr (LPR >= 2) v = lane_butterfly_add<1>(v);
   return v;
 }

@@ -322,8 +322,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void conv3d_k3_kernel(ConvParams p) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       float v = rowsq[tt];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      v = lane_xor16_sum(v);
+      v = lane_xor32_sum(v);
       if (lane < 16) part[((wm * TT + tt) * 16 + lane) * WN + wn] = v;
     }
     __syncthreads();

@@ -101,20 +101,31 @@ __global__ __launch_bounds__(256) void norm_scale_kernel(
   if (row >= M) return;
   const int col0 = piece * (512 * CH) + lane * 8;
   const bf16* xr = x + (size_t)row * D + col0;
+  // Every load of the wave is requested before the reduction, the token -> row index first (it is the oldest load, so the
+  // modulation loads that depend on it wait for it alone): one memory latency in the chain - two with a row map - not three.
+  const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
   bf16x8 v[CH];
 #pragma unroll
   for (int i = 0; i < CH; ++i) v[i] = *(const bf16x8*)(xr + i * 512);
-  float ss = 0.f;
-  for (int i = lane; i < NP; i += 64) ss += sumsq[(size_t)row * ss_ld + i];
+  const float ss0 = lane < NP ? sumsq[(size_t)row * ss_ld + lane] : 0.f;
+  bf16x8 scv[CH], shv[CH];
+  if (scale) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      scv[i] = *(const bf16x8*)(scale + mrow + col0 + i * 512);
+      shv[i] = *(const bf16x8*)(shift + mrow + col0 + i * 512);
+    }
+  }
+  float ss = ss0;
+  for (int i = lane + 64; i < NP; i += 64) ss += sumsq[(size_t)row * ss_ld + i];
   const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
-  const size_t mrow = scale ? (size_t)(mod_row ? mod_row[row] : 0) * mod_stride : 0;
   bf16* yr = y + (size_t)row * D + col0;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     bf16x8 o;
     if (scale) {
-      const bf16x8 sc = *(const bf16x8*)(scale + mrow + col0 + i * 512);
-      const bf16x8 sh = *(const bf16x8*)(shift + mrow + col0 + i * 512);
+      const bf16x8 sc = scv[i];
+      const bf16x8 sh = shv[i];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float n = rbf((float)v[i][j] * rstd);
@@ -222,16 +233,20 @@ __global__ __launch_bounds__(256) void qknorm_rope_ss_kernel(
   }
   float ss = 0.f;
   for (int i = lane; i < NP; i += 64) ss += sumsq[(size_t)row * ss_ld + sgi * NP + i];
+  // weights and the rotation table are requested before the reduction (they do not depend on it)
+  bf16x8 wa, wb;
+  f32x4 c0, c1, s0, s1;
+  if (act) {
+    wa = *(const bf16x8*)(wr + base);
+    wb = *(const bf16x8*)(wr + base + 64);
+    if (cosb) {
+      const size_t off = ((size_t)head * T + t) * 64 + j0;
+      c0 = *(const f32x4*)(cosb + off); c1 = *(const f32x4*)(cosb + off + 4);
+      s0 = *(const f32x4*)(sinb + off); s1 = *(const f32x4*)(sinb + off + 4);
+    }
+  }
   const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
   if (!act) return;
-  const bf16x8 wa = *(const bf16x8*)(wr + base);
-  const bf16x8 wb = *(const bf16x8*)(wr + base + 64);
-  f32x4 c0, c1, s0, s1;
-  if (cosb) {
-    const size_t off = ((size_t)head * T + t) * 64 + j0;
-    c0 = *(const f32x4*)(cosb + off); c1 = *(const f32x4*)(cosb + off + 4);
-    s0 = *(const f32x4*)(sinb + off); s1 = *(const f32x4*)(sinb + off + 4);
-  }
   bf16x8 oa, ob;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {

@@ -356,8 +356,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       }
       if (want_ss) {
         // the wave's 64 columns of row m: 16 values per lane, then the four lanes sharing (lane & 15); fixed order
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = lane_xor16_sum(ss);
+        ss = lane_xor32_sum(ss);
         // (a wave whose 64-column block lies past N - the last column tile when N % 256 != 0 - has nothing to report:
         // its slot would be the next row's first partial)
         if (lane < 16 && n0 + wn * 64 < p.N) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
@@ -707,8 +707,8 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           float v = ss[b];
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
+          v = lane_xor16_sum(v);
+          v = lane_xor32_sum(v);
           if (lane < 16 && m < p.M) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 128) >> 6) + b] = v;
         }
       }

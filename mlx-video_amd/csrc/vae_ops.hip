@@ -35,8 +35,7 @@ __global__ __launch_bounds__(256) void pixelnorm_act_kernel(
       sq += rbf(f * f);
     }
   }
-#pragma unroll
-  for (int off = LPR / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+  sq = group_sum<LPR>(sq);                       // permlane / DPP butterfly, same bits as the __shfl_xor one (common.h)
   const float m = rbf(sq / (float)C);
   const float sd = rbf(sqrtf(rbf(m + eps)));
   // x / sd for the whole row: reciprocal once, then one Newton step per element (q = x*r; q += (x - q*sd)*r).
