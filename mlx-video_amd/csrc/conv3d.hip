@@ -425,9 +425,15 @@ struct KwGeom {
 // issued one group ahead of their use (flat order W0, A0[*], W1, A1[*], W2, A2[*]); the stage's LDS-DMA pieces are
 // sprinkled one per group; and the last two groups of every stage are deferred until after the next barrier (their
 // operands are in registers), so they execute while the first fragment reads of the new stage are in flight.
+#ifndef LTXK_KW_PD
+#define LTXK_KW_PD 1      // fragment reads run this many MFMA groups ahead of their use
+#endif
+#ifndef LTXK_KW_DG
+#define LTXK_KW_DG 2      // trailing MFMA groups of a stage deferred past the next barrier
+#endif
 template <int TT, int NPIECES>
 struct KwPipe {
-  static constexpr int NS = 3, PD = 1, DG = 2;
+  static constexpr int NS = 3, PD = LTXK_KW_PD, DG = LTXK_KW_DG;
   static constexpr int NG = NS * TT, RPS = 4 + TT, TOTAL = NS * RPS;
   static constexpr int PPG = (NPIECES + NG - 1) / NG;
   static_assert(TT >= 2, "deferred groups must lie in the last sub-step");
