@@ -78,6 +78,20 @@ def main():
     vid = OV.vae_decode(z.float(), Wd_, O.BF16, layers_per_block=1)
     np.savez_compressed(os.path.join(HERE, "vae_decode_tiny.npz"), seed_weights=77, latent=f32(z), video=f32(vid).astype(np.float16),
                         uint8=OV.to_uint8(vid[0], O.BF16).numpy())
+
+    # ---- round 3: attention under both rounding policies (oracle/dit.py::sdpa), incl. a ragged key count and a spiked row;
+    # the area-resize restatement (oracle/media.py) at an integer and a fractional factor ----
+    ga = torch.Generator().manual_seed(9)
+    q = torch.randn(1, 70, 256, generator=ga).to(torch.bfloat16)
+    k = torch.randn(1, 150, 256, generator=ga).to(torch.bfloat16)
+    v = torch.randn(1, 150, 256, generator=ga).to(torch.bfloat16)
+    k[0, 99] = q[0, 7] * 3.0
+    np.savez_compressed(os.path.join(HERE, "sdpa_policies.npz"), q=f32(q), k=f32(k), v=f32(v), heads=2,
+                        out_fp32P=f32(O.sdpa(q.float(), k.float(), v.float(), 2, O.BF16)),
+                        out_flash=f32(O.sdpa(q.float(), k.float(), v.float(), 2, O.BF16_FLASH)))
+    from oracle import media as OM
+    fr = np.random.default_rng(11).random((2, 3, 24, 36), dtype=np.float32) * 2 - 1
+    np.savez_compressed(os.path.join(HERE, "area_resize.npz"), frames=fr, half=OM.resize_area(fr, 12, 18), frac=OM.resize_area(fr, 16, 20))
     print("golden fixtures written to", HERE)
 
 
