@@ -366,6 +366,8 @@ KW_CASES = [  # (B, D, H, W, Cin, Cout, causal, pad_mode, residual); every case 
     (1, 2, 96, 192, 128, 512, 2, 0, False),      # zero temporal halo (upsampler mode), 4 column tiles
     (1, 2, 260, 65, 128, 128, 0, 1, True),       # W = 65: odd width, two frames
     (1, 3, 100, 131, 192, 128, 2, 1, True),      # Cin = 192 (six 32-channel blocks), W = 131, zero temporal halo + reflect
+    (1, 2, 60, 300, 128, 128, 0, 1, False),      # W = 300 > the 256-row tile: tiles start mid-row (left neighbour is a real voxel, not a halo)
+    (1, 2, 70, 257, 64, 128, 1, 0, True),        # W = 257, zero padding: every tile boundary drifts by one voxel per image row
 ]
 
 
