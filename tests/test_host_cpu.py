@@ -417,3 +417,17 @@ def test_video_file_decode_through_ffmpeg(tmp_path, monkeypatch):
     probe.write_text("#!/bin/sh\necho '{}'\n")
     with pytest.raises(ValueError, match="Unable to open video"):
         media.decode_video_ffmpeg(vid)
+
+
+def test_product_library_reads_no_environment():
+    """include/ltxk.h, Conventions: "no global mutable state".  The A/B switches live in libltxk_ab.so (-DLTXK_AB) only: the
+    product library must not even import getenv."""
+    import shutil, subprocess
+    from mlx_video_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    def imports(path):
+        out = subprocess.run([nm, "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+    assert "getenv" not in imports(_lib.LIB_PATH) and "secure_getenv" not in imports(_lib.LIB_PATH)
+    if os.path.exists(_lib.AB_LIB_PATH):
+        assert "getenv" in imports(_lib.AB_LIB_PATH)          # ... and the measurement build is the one that does
