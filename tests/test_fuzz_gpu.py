@@ -138,3 +138,37 @@ def test_conv3d_fuzz(dev, cin, cout, causal, reflect, shape):
     torch.cuda.synchronize()
     parity.auto(rel_l2(cf(out), ref), 4e-3)
     parity.auto(rel_l2(cf(out_r), O.BF16.r(ref + res.float())), 4e-3)
+
+
+def _kw_conv_cases(n=10):
+    """Seeded shapes that take the kw-reuse convolution kernel (conv3d.hip: Cout <= 128, W >= 64, more than 128 tiles of 256
+    rows): odd widths and heights, 1-2 batch items, every channel-block count the ABI allows."""
+    rnd = random.Random(303)
+    cases = []
+    while len(cases) < n:
+        b, d = rnd.randint(1, 2), rnd.randint(1, 4)
+        w = rnd.randint(64, 210)
+        h = max(2, -(-33500 // (b * d * w)) + rnd.randint(0, 6))          # B*D*H*W > 128 * 256 rows
+        cases.append((64 * rnd.randint(1, 3), rnd.choice([8, 48, 64, 104, 128]), rnd.choice([0, 1]), rnd.choice([False, True]), (b, d, h, w)))
+    return cases
+
+
+@pytest.mark.parametrize("cin,cout,causal,reflect,shape", _kw_conv_cases())
+def test_conv3d_kw_form_fuzz_vs_oracle(dev, cin, cout, causal, reflect, shape):
+    from mlx_video_amd import video_vae as V
+    b, d, h, w = shape
+    assert b * d * h * w > 128 * 256
+    g = torch.Generator().manual_seed(cin * 7 + cout * 3 + d * h + w)
+    x = torch.randn(b, cin, d, h, w, generator=g).to(BF)
+    wt = (torch.randn(cout, 3, 3, 3, cin, generator=g) / (27 * cin) ** 0.5).to(BF)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(BF)
+    res = torch.randn(b, cout, d, h, w, generator=g).to(BF)
+    ref = OV.causal_conv3d(x.float(), wt, bias, O.BF16, bool(causal), reflect)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous()
+    cf = lambda t: t.permute(0, 4, 1, 2, 3).contiguous()
+    mode = V.PAD_REFLECT if reflect else V.PAD_ZEROS
+    out = V.conv3d(cl(x).to(dev), wt.to(dev), bias.to(dev), bool(causal), mode)
+    out_r = V.conv3d(cl(x).to(dev), wt.to(dev), bias.to(dev), bool(causal), mode, resid=cl(res).to(dev))
+    torch.cuda.synchronize()
+    parity.auto(rel_l2(cf(out), ref), 4e-3)
+    parity.auto(rel_l2(cf(out_r), O.BF16.r(ref + res.float())), 4e-3)
