@@ -2,6 +2,10 @@
 // Replaces mx.fast.scaled_dot_product_attention (attention.py:47) and the head reshapes
 // around it (attention.py:24-33,50-51).
 //
+// Two kernels of the same structure live here: flash_attn16_kernel on v_mfma_f32_16x16x32_bf16 (fa_body16, round 3, the
+// one ltxk_flash_attn launches) and flash_attn_kernel on v_mfma_f32_32x32x16_bf16 (fa_body, rounds 1-2; kept for the A/B
+// build, LTXK_FA_MFMA=32).  The 32x32 form is described first; fa_body16's header has the 16x16 operand map.
+//
 // Structure (gfx950): workgroup = 4 waves, each wave owns 32 query rows; K/V tiles of 64 keys
 // are staged by LDS-DMA (global_load_lds_dwordx4) into a 2-deep LDS ring, one barrier per tile.
 // Per wave and tile:
@@ -805,7 +809,9 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // splitting the keys four ways - halves of every tile x even / odd tiles): 80.1 against 73.4 us at 1280^2, 65.5 against 58.2 at
   // 1280x1024 - and without any tail split the launch takes 74.9 us: two workgroups on a CU share its matrix pipe, so the
   // short round's lone workgroups already run nearly twice as fast, and there is little left for a finer split to win.
-  // LTXK_FA_XCD={1,0} remains in the A/B build.
+  // Round 3: the 16x16x32 formulation (fa_body16) - first form equal at 5184^2 (834.7 vs 834.5 us: 13 % higher held clock spent
+  // on 18 % more VALU issue), after dropping the cross-lane exchange from the deferral test and the packed fp32 adds 795 vs 830 us
+  // at 5184^2 and 67.4 vs 70.1 us at 1280^2: it ships (profiles/r03_attn_*).  LTXK_FA_XCD={1,0}, LTXK_FA_MFMA={16,32} remain in the A/B build.
   const int xcd_map = LTXK_AB_INT("LTXK_FA_XCD", 1);
   p.QT = (Tq + 127) / 128;
   p.xcd = (xcd_map && (B * H) % 8 == 0) ? 1 : 0;
