@@ -827,8 +827,13 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   }
   const int tiles = p.QT * B * H;
   p.n_full = tiles; p.rem = 0;
-  if (split && tiles % slots != 0 && 2 * (tiles % slots) <= slots) {
-    p.rem = tiles % slots;
+  if (split && tiles % slots != 0) {
+    // r tiles in the short last round.  r <= slots/2: split them all (2r workgroups).  r > slots/2 (round 3; e.g. one
+    // B=1 forward of the CFG-pair split: 320 tiles for 512 slots): split the slots - r tiles that fill the round exactly -
+    // 2 (slots - r) half workgroups + (2r - slots) whole ones = slots workgroups, no CU left with two whole tiles beside
+    // CUs that have one.
+    const int r = tiles % slots;
+    p.rem = 2 * r <= slots ? r : (LTXK_AB_INT("LTXK_FA_FILL", 1) ? slots - r : 0);
     p.n_full = tiles - p.rem;
   }
   const dim3 grid((unsigned)(p.n_full + 2 * p.rem));
