@@ -418,7 +418,9 @@ def main() -> None:
         result["cfgpair_one_gpu_prediction"] = cfgpair_pred
         if "N1280" in cfgpair_pred:
             result["forward_b1_ms"] = cfgpair_pred["N1280"]["forward_b1_ms"]
-            result["cfgpair_predicted_efficiency"] = cfgpair_pred["N1280"]["cfgpair_predicted_efficiency"]
+            # the split is what BASELINE config 4 uses (512x512x97: N=3328 tokens per forward); N=1280 is this bench's own shape
+            result["cfgpair_predicted_efficiency"] = {"N1280": cfgpair_pred["N1280"]["cfgpair_predicted_efficiency"],
+                                                      "N3328_config4": cfgpair_pred.get("N3328", {}).get("cfgpair_predicted_efficiency")}
     if batch2 is not None:
         result["two_seed_batch"] = batch2
 
