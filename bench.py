@@ -433,7 +433,10 @@ def main() -> None:
                 result["roofline_by_family"]["conv3d_k3"] = {
                     "kernel": "ltxk::conv3d_k3_kw_kernel + conv3d_k3_kernel (2*27*Cin*Cout*voxels FLOP per launch)", "bound": "mfma",
                     "achieved": vres["vae_conv3d_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                    "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None}
+                    "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                    "launches": vres.get("vae_conv3d_launches"),
+                    "avg_ms": (vres["vae_kernel_breakdown_ms"]["conv3d_k3"] / vres["vae_conv3d_launches"]
+                               if vres.get("vae_conv3d_launches") and "vae_kernel_breakdown_ms" in vres else None)}
         except ImportError:
             result["vae_decode_fps"] = None
 
