@@ -486,6 +486,11 @@ static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t st
 }
 
 // Row-tile height: minimise (rounds over 256 CUs) x (tile rows + fixed per-tile overhead).
+// (Round 3, tried and removed: "whole rounds first" - the rows of the whole 256-CU rounds as 160-row tiles, the remaining rows
+// as a second launch at their own best height.  The model below prices it 5-9 % cheaper at M=3328 / 5184 / 6656, N=4096;
+// measured -0.5...-2.3 % at M=3328 / 6656 and +3...4 % at M=5184 (profiles/r03_gemm_rounds_ab.log): a part-filled last round
+// costs less than the model's whole round - the busy CUs run at a higher clock - and the second launch pays its own fill,
+// epilogue and boundary.)
 static int pick_tt(int M, int N) {
   const int cand[5] = {5, 4, 3, 2, 1};
   const int CT = (N + GEMM_BN - 1) / GEMM_BN;
