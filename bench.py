@@ -47,16 +47,52 @@ def dit_forward_flops(N: int, B: int = 1, D: int = 4096, FF: int = 16384, S: int
     return float(B) * (L * per_block + extra)
 
 
+def _strip_comments(text: str) -> str:
+    """C/C++ source without // and /* */ comments and blank lines (string literals respected): a comment edit must not
+    invalidate the PMC artefacts stamped with source_sha()."""
+    out, i, n, state = [], 0, len(text), 0          # state: 0 code, 1 string, 2 char, 3 line comment, 4 block comment
+    while i < n:
+        c, d = text[i], text[i + 1] if i + 1 < n else ""
+        if state == 0:
+            if c == "/" and d == "/":
+                state, i = 3, i + 2
+                continue
+            if c == "/" and d == "*":
+                state, i = 4, i + 2
+                continue
+            if c == '"':
+                state = 1
+            elif c == "'":
+                state = 2
+            out.append(c)
+        elif state in (1, 2):
+            out.append(c)
+            if c == "\\" and i + 1 < n:
+                out.append(d)
+                i += 1
+            elif (state == 1 and c == '"') or (state == 2 and c == "'"):
+                state = 0
+        elif state == 3:
+            if c == "\n":
+                out.append(c)
+                state = 0
+        elif state == 4 and c == "*" and d == "/":
+            state, i = 0, i + 1
+        i += 1
+    return "\n".join(ln.rstrip() for ln in "".join(out).splitlines() if ln.strip())
+
+
 def source_sha() -> str:
-    """Hash of the kernel sources the loaded libltxk.so was built from (the .so itself is not tracked): PMC artefacts
-    under profiles/ carry the hash they were measured on, and are only quoted while it still matches."""
+    """Hash of the kernel sources (comments and blank lines stripped) the loaded libltxk.so was built from (the .so itself
+    is not tracked): PMC artefacts under profiles/ carry the hash they were measured on, and are only quoted while it
+    still matches."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "mlx-video_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".hip", ".h", ".cpp")):
             h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+            h.update(_strip_comments(open(os.path.join(csrc, name), encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -431,3 +431,14 @@ def test_product_library_reads_no_environment():
     assert "getenv" not in imports(_lib.LIB_PATH) and "secure_getenv" not in imports(_lib.LIB_PATH)
     if os.path.exists(_lib.AB_LIB_PATH):
         assert "getenv" in imports(_lib.AB_LIB_PATH)          # ... and the measurement build is the one that does
+
+
+def test_bench_source_hash_ignores_comments():
+    """bench.source_sha() stamps the PMC artefacts under profiles/ (bench.py quotes `roofline.traffic` only while the kernel
+    sources still hash to it): comment / blank-line edits must not change it, code edits must."""
+    import bench
+    a = 'int a = 1; // c1\\n/* block\\n more */ const char* s = "// kept"; char q = \\'"\\'; // x\\n\\n  int b; /* y */ int c;\\n'
+    assert bench._strip_comments(a) == 'int a = 1;\\n const char* s = "// kept"; char q = \\'"\\';\\n  int b;  int c;'
+    assert bench._strip_comments(a + "// more\\n\\n") == bench._strip_comments(a)
+    assert bench._strip_comments(a + "int d;\\n") != bench._strip_comments(a)
+    assert len(bench.source_sha()) == 16
