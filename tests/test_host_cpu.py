@@ -437,8 +437,8 @@ def test_bench_source_hash_ignores_comments():
     """bench.source_sha() stamps the PMC artefacts under profiles/ (bench.py quotes `roofline.traffic` only while the kernel
     sources still hash to it): comment / blank-line edits must not change it, code edits must."""
     import bench
-    a = 'int a = 1; // c1\\n/* block\\n more */ const char* s = "// kept"; char q = \\'"\\'; // x\\n\\n  int b; /* y */ int c;\\n'
-    assert bench._strip_comments(a) == 'int a = 1;\\n const char* s = "// kept"; char q = \\'"\\';\\n  int b;  int c;'
-    assert bench._strip_comments(a + "// more\\n\\n") == bench._strip_comments(a)
-    assert bench._strip_comments(a + "int d;\\n") != bench._strip_comments(a)
+    a = "int a = 1; // c1\n/* block\n more */ const char* s = \"// kept\"; char q = 'x'; // x\n\n  int b; /* y */ int c;\n"
+    assert bench._strip_comments(a) == "int a = 1;\n const char* s = \"// kept\"; char q = 'x';\n  int b;  int c;"
+    assert bench._strip_comments(a + "// more\n\n") == bench._strip_comments(a)
+    assert bench._strip_comments(a + "int d;\n") != bench._strip_comments(a)
     assert len(bench.source_sha()) == 16
