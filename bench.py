@@ -118,8 +118,48 @@ def cpu_baseline_block(threads: int):
     dt = (time.perf_counter() - t0) / REPS
     # "port": this repository's own torch-CPU fp32 restatement of the reference step (oracle/), NOT the reference's MLX-CPU
     # path - MLX is not installable here
-    return {"value": 1.0 / (dt * 48), "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": f"{REPS} of 48 DiT blocks (oracle fp32, B=2 CFG pair, N=1280, S=1024, D=4096) = {dt * REPS:.1f} s, scaled x48/{REPS}"}
+    res = {"value": 1.0 / (dt * 48), "unit": "steps/s", "cores": threads, "kind": "port",
+           "sample": f"{REPS} of 48 DiT blocks (oracle fp32, B=2 CFG pair, N=1280, S=1024, D=4096) = {dt * REPS:.1f} s, scaled x48/{REPS}"}
+    del W, x, ts, ctx
+    # ---- VAE leg (BASELINE.md "CPU-baseline plan"): the oracle's fp32 decode of a (1,128,2,4,4) latent -> 9 x 128 x 128 frames,
+    # full depth (5 res blocks per stage), 0.212 TFLOP; decoder.py:361-450 restated in oracle/vae.py ----
+    from oracle import vae as OV
+    Wv = OV.make_decoder_weights(seed=1234, dtype=torch.float32)
+    zl = torch.randn(1, 128, 2, 4, 4, generator=g)
+    OV.vae_decode(zl, Wv, O.F32)                                     # warm-up (thread pool, allocator)
+    VREPS = 2
+    t0 = time.perf_counter()
+    for _ in range(VREPS):
+        vid = OV.vae_decode(zl, Wv, O.F32)
+    dtv = (time.perf_counter() - t0) / VREPS
+    res["vae"] = {"value": vid.shape[2] / dtv, "unit": "frames/s", "cores": threads, "kind": "port", "seconds_per_decode": dtv,
+                  "tflops": 0.212 / dtv,
+                  "sample": f"{VREPS} fp32 decodes of a (1,128,2,4,4) latent -> {vid.shape[2]} x {vid.shape[3]} x {vid.shape[4]} frames "
+                            f"(oracle/vae.py::vae_decode, 5 res blocks per stage, 0.212 TFLOP each); the GPU leg decodes 33 x 512 x 512 "
+                            f"(11.26 TFLOP) - compare TFLOP/s, not frames/s"}
+    del Wv
+    # ---- config 1 of BASELINE.json as BASELINE.md describes it: ONE dev step at 128x128x9 (N=32 tokens, CFG pair = 2 forwards,
+    # context 1024x3840), full-width blocks, L=2 end to end (prepare + blocks + head + CFG + x0 + Euler); the 48-layer figure
+    # adds 23 more pairs of blocks at the measured per-block time (13 B fp32 parameters = 52 GB are not materialised) ----
+    cfg2 = O.DiTConfig(num_layers=2)
+    W2 = O.make_weights(cfg2, seed=1234, dtype=torch.float32)
+    lat = torch.randn(1, 128, 2, 4, 4, generator=g)
+    cpos, cneg = torch.randn(1, 1024, cfg2.caption_channels, generator=g), torch.randn(1, 1024, cfg2.caption_channels, generator=g)
+    pos1 = O.create_position_grid(1, 2, 4, 4)
+    sig = [1.0, 0.0]
+    t0 = time.perf_counter()
+    O.denoise_dev(lat, pos1, cpos, cneg, W2, cfg2, sig, O.F32, 4.0)
+    dt2 = time.perf_counter() - t0
+    cfg0 = O.DiTConfig(num_layers=0)
+    W0 = {k: v for k, v in W2.items() if not k.startswith("transformer_blocks.")}
+    t0 = time.perf_counter()
+    O.denoise_dev(lat, pos1, cpos, cneg, W0, cfg0, sig, O.F32, 4.0)
+    dt0 = time.perf_counter() - t0
+    res["dit_config1"] = {"seconds_per_step_L2": dt2, "seconds_per_step_L0_prepare_and_head": dt0,
+                          "steps_per_s_L48_extrapolated": 1.0 / (dt0 + (dt2 - dt0) * 24.0), "cores": threads, "kind": "port",
+                          "sample": "one dev step 128x128x9 (N=32, S=1024, CFG 4.0 = 2 forwards), oracle fp32, L=2 measured; "
+                                    "L=48 = prepare/head time + 24 x the two blocks' time"}
+    return res
 
 
 def time_forward(model, B: int, N: int, reps: int = 3, dev=None):
@@ -151,15 +191,41 @@ def time_forward(model, B: int, N: int, reps: int = 3, dev=None):
     return sorted(ts)[len(ts) // 2]
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (torch.cuda.device_count() falls back to
+    hipGetDeviceCount - which initialises it - whenever amdsmi is unavailable): the KFD topology lists every agent, GPUs are
+    the nodes with simd_count > 0; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow that.  -1 = unknown."""
+    import glob
+    try:
+        n = 0
+        for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            props = dict(ln.split(None, 1) for ln in open(f).read().splitlines() if " " in ln)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return -1
+    if n == 0:
+        return -1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` started WITHOUT torch.distributed.run (no RANK in the environment): this parent - which
     never touches the GPU - starts the N ranks itself (one child process per GPU, the same environment torchrun would give
-    them), relays rank 0's JSON line and exits with the first non-zero child code.  It never prints a line of its own, so an
-    N-GPU request cannot come back as an n_gpus=1 measurement."""
+    them), relays rank 0's JSON line and exits non-zero as soon as any rank fails (the others are then terminated: a rank
+    that dies early must not leave the rest waiting for the process-group timeout).  It never prints a line of its own, so
+    an N-GPU request cannot come back as an n_gpus=1 measurement.  (Under `rocprofv3 -- python bench.py --gpus N` the
+    profiler's preloaded library has initialised the GPU in this parent already: profile multi-GPU runs with an external
+    launcher, one rocprofv3 per rank - profiles/README.md.)"""
     import socket
     import subprocess
     rehearsal = os.environ.get("LTXK_BENCH_REHEARSAL") == "1"
-    have = torch.cuda.device_count()            # counting devices does not initialise the GPU runtime on this image
+    have = visible_gpu_count()
+    if have < 0:
+        have = torch.cuda.device_count()
     if have < n and not rehearsal:
         print(f"[bench] --gpus {n} but only {have} GPU(s) are visible; refusing to measure fewer", file=sys.stderr)
         return 2
@@ -172,14 +238,31 @@ def self_launch(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
+    # rank 0's stdout is drained by a thread so that polling every child never blocks on a full pipe
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is not None:
+                live.remove(pr)
+                rc = rc or code
+    for pr in live:                      # a rank failed: stop the others (exact PIDs started above)
+        pr.terminate()
+    for pr in live:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    rd.join(timeout=30)
     if rc == 0:
         # rank 0's result line only (a rehearsal over gloo also prints connection chatter on stdout)
-        lines = [ln for ln in out0.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        lines = [ln for ln in "".join(out0).splitlines() if ln.startswith("{") and '"metric"' in ln]
         if not lines:
             print("[bench] rank 0 printed no result line", file=sys.stderr)
             return 3
@@ -326,8 +409,8 @@ def main() -> None:
     # seed i, one forward each, RCCL all-gather of the two velocities per step, fused tail on both (sharding.py) ----
     cfgpair = None
     if dist is not None and world >= 2 and world % 2 == 0 and pg_shard is None and os.environ.get("LTXK_BENCH_CFGPAIR", "1") != "0":
+        from mlx_video_amd.sharding import CfgPairSharding
         try:
-            from mlx_video_amd.sharding import CfgPairSharding
             sh = CfgPairSharding(dist, rank, world)
             g3 = torch.Generator(device=dev).manual_seed(42 + rank // 2)
             lat_p = torch.randn((1, 128, Fl, Hl, Wl), generator=g3, device=dev).to(torch.bfloat16)
@@ -344,9 +427,11 @@ def main() -> None:
             cfgpair = {"value": (world // 2) * args.steps / dtp, "unit": "denoise steps/s (whole job; one seed per rank PAIR)",
                        "ms_per_step": 1000.0 * dtp / args.steps, "pairs": world // 2, "finite": bool(torch.isfinite(out_p.float()).all()),
                        "collective": "all_gather_into_tensor of 2 x (1,N,128) bf16 per step per pair (RCCL)"}
-        except Exception as e:           # the secondary line must never cost the primary one
+        except dist.DistError as e:
+            # Only a failure of the process-group machinery (group creation, the collective's backend, the network) may cost
+            # the secondary line alone.  Anything else - a HIP fault, a capture error, a Python bug - ends the run: the
+            # VAE leg below must not execute on a context a kernel has just poisoned.
             cfgpair = {"error": repr(e)[:300]}
-
 
     # ---- one-GPU prediction of the CFG-pair split (N=1 only): a pair rank runs ONE B=1 forward per step where this
     # rank runs the B=2 forward; expected 2-GPU efficiency of the split = t(B=2) / (2 * t(B=1)), before any RCCL cost.

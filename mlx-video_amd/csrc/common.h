@@ -145,14 +145,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Sum over aligned groups of LPR lanes (LPR = 16, 32 or 64), butterfly from LPR/2 down.
+// Sum over aligned groups of LPR lanes, butterfly from LPR/2 down.  LPR = 16, 32 or 64 take the single-instruction exchanges
+// above.  The DPP row rotate equals lane ^ OFF only once the value is symmetric under every larger offset inside the row of
+// 16, which a butterfly that STARTS below 8 never establishes (LPR = 8: row_ror:4 would mix the row's two groups), so
+// narrower groups keep the plain __shfl_xor exchange.
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-  if constexpr (LPR >= 64) v = lane_butterfly_add<32>(v);
-  if constexpr (LPR >= 32) v = lane_butterfly_add<16>(v);
-  if constexpr (LPR >= 16) v = lane_butterfly_add<8>(v);
-  if constexpr (LPR >= 8) v = lane_butterfly_add<4>(v);
-  if constexpr (LPR >= 4) v = lane_butterfly_add<2>(v);
-  if constexpr (LPR >= 2) v = lane_butterfly_add<1>(v);
+  static_assert(LPR == 1 || LPR == 2 || LPR == 4 || LPR == 8 || LPR == 16 || LPR == 32 || LPR == 64, "group width");
+  if constexpr (LPR >= 16) {
+    if constexpr (LPR >= 64) v = lane_butterfly_add<32>(v);
+    if constexpr (LPR >= 32) v = lane_butterfly_add<16>(v);
+    v = lane_butterfly_add<8>(v);
+    v = lane_butterfly_add<4>(v);
+    v = lane_butterfly_add<2>(v);
+    v = lane_butterfly_add<1>(v);
+  } else {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  }
   return v;
 }

@@ -1,7 +1,7 @@
 """Conditioning-input I/O (mlx_video/utils.py:529-715): image / frame-sequence loading,
-LANCZOS resize to the stage resolution and [-1,1] normalisation into the (1,3,F,H,W) tensors the VAE
-encoder takes.  Host-side PIL/numpy work, as in the reference; video *files* need cv2/PyAV (absent in this
-image), so video conditionings are taken from a directory of frames or an .npy array instead."""
+LANCZOS resize of images, cv2.INTER_AREA resize of video frames (evaluated here from OpenCV's published coefficient
+tables - cv2 itself is not in this image) and [-1,1] normalisation into the (1,3,F,H,W) tensors the VAE encoder
+takes.  Host-side PIL/numpy work, as in the reference; video FILES are decoded by an ffmpeg child process."""
 from __future__ import annotations
 
 from pathlib import Path
@@ -36,6 +36,73 @@ def image_to_conditioning(image: np.ndarray) -> torch.Tensor:
     return t * 2.0 - 1.0
 
 
+def area_taps(ssize: int, dsize: int):
+    """One axis of cv2.resize(..., INTER_AREA) as a tap table: (idx, w), both (dsize, T); destination d =
+    sum_t w[d,t] * src[idx[d,t]].  Shrinking (ssize >= dsize) is OpenCV's area table (imgproc/resize.cpp,
+    computeResizeAreaTab): d covers the source interval [d*scale, (d+1)*scale), whole pixels inside weigh 1/cell, the two
+    cut pixels their overlap/cell with cell = min(scale, ssize - d*scale), overlaps below 1e-3 dropped.  Enlarging is
+    what INTER_AREA falls back to there: two taps, sx = floor(d*scale), fx = (d+1) - (sx+1)/scale (0 if negative, else
+    its fractional part), the last source pixel repeated.  The same coefficients as ltxk_resize_area on the device."""
+    scale = ssize / dsize
+    d = np.arange(dsize, dtype=np.float64)
+    if dsize > ssize:
+        sx = np.floor(d * scale).astype(np.int64)
+        fx = (d + 1.0) - (sx + 1.0) / scale
+        fx = np.where(fx <= 0, 0.0, fx - np.floor(fx))
+        edge = sx >= ssize - 1
+        sx, fx = np.where(edge, ssize - 1, sx), np.where(edge, 0.0, fx)
+        idx = np.stack([sx, np.minimum(sx + 1, ssize - 1)], 1)
+        return idx, np.stack([1.0 - fx, fx], 1).astype(np.float32)
+    f1 = d * scale
+    f2 = f1 + scale
+    cell = np.minimum(scale, ssize - f1)
+    s2 = np.minimum(np.floor(f2), ssize - 1).astype(np.int64)
+    s1 = np.minimum(np.ceil(f1).astype(np.int64), s2)
+    T = int(np.max(s2 - s1)) + 2
+    t = np.arange(T)[None, :]
+    idx = s1[:, None] - 1 + t                                      # tap 0 = the cut pixel on the left
+    w = np.where((t >= 1) & (idx < s2[:, None]), 1.0 / cell[:, None], 0.0)
+    left = np.where(s1 - f1 > 1e-3, (s1 - f1) / cell, 0.0)
+    right = np.where(f2 - s2 > 1e-3, np.minimum(np.minimum(f2 - s2, 1.0), cell) / cell, 0.0)
+    w[:, 0] = left
+    np.put_along_axis(w, (s2 - s1 + 1)[:, None], right[:, None], 1)
+    return np.clip(idx, 0, ssize - 1), w.astype(np.float32)
+
+
+def _apply_taps_rows(a: np.ndarray, idx: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """sum_t w[:,t] * a[idx[:,t]] along axis 0, taps added in table order (cv2's loop order); a tap whose indices form
+    an arithmetic progression (every tap of an integer factor) is a strided view instead of a gather."""
+    acc = None
+    for t in range(idx.shape[1]):
+        if not w[:, t].any():
+            continue
+        i = idx[:, t]
+        step = int(i[1] - i[0]) if len(i) > 1 else 1
+        src = a[i[0]: i[-1] + 1: step] if step > 0 and np.array_equal(i, i[0] + step * np.arange(len(i))) else a[i]
+        term = src * w[:, t].reshape((-1,) + (1,) * (a.ndim - 1))
+        acc = term if acc is None else np.add(acc, term, out=acc)
+    return acc
+
+
+def resize_area(frames: np.ndarray, height: int, width: int) -> np.ndarray:
+    """cv2.resize(frame, (width, height), interpolation=cv2.INTER_AREA) for every frame of an (F,H,W,C) array
+    (utils.py:597-598 on the decoded uint8 frames, utils.py:699-705 on float frames): horizontal pass then vertical pass
+    in fp32; uint8 input gives uint8 output, rounded to nearest-even as cv2's saturate_cast does.  (One filter for every
+    container a conditioning clip can arrive in: tensors take the same table through ltxk_resize_area.)"""
+    F, H, W, C = frames.shape
+    tx = area_taps(W, width) if W != width else None
+    ty = area_taps(H, height) if H != height else None
+    out = np.empty((F, height, width, C), frames.dtype if frames.dtype == np.uint8 else np.float32)
+    for i in range(F):
+        a = frames[i].astype(np.float32)
+        if tx is not None:                                 # columns -> rows so that every tap reads whole contiguous rows
+            a = _apply_taps_rows(np.ascontiguousarray(a.transpose(1, 0, 2)), *tx).transpose(1, 0, 2)
+        if ty is not None:
+            a = _apply_taps_rows(np.ascontiguousarray(a), *ty)
+        out[i] = np.clip(np.rint(a), 0, 255) if frames.dtype == np.uint8 else a
+    return out
+
+
 VIDEO_SUFFIXES = (".mp4", ".mov", ".mkv", ".webm", ".avi", ".m4v", ".gif")
 
 
@@ -58,7 +125,9 @@ def decode_video_ffmpeg(path: Union[str, Path], frame_cap: Optional[int] = None)
         w, h = int(st["width"]), int(st["height"])
     except (ValueError, KeyError, IndexError):
         raise ValueError(f"Unable to open video: {path}")
-    cmd = [ffmpeg, "-v", "error", "-i", str(path)] + (["-frames:v", str(int(frame_cap))] if frame_cap else []) + \
+    # -noautorotate: ffprobe reports the CODED frame size; with rotation side data ffmpeg would otherwise hand back
+    # transposed frames that reshape into garbage (cv2.VideoCapture's orientation handling is not reproduced: parity unpinned)
+    cmd = [ffmpeg, "-v", "error", "-noautorotate", "-i", str(path)] + (["-frames:v", str(int(frame_cap))] if frame_cap else []) + \
           ["-f", "rawvideo", "-pix_fmt", "rgb24", "-"]
     out = subprocess.run(cmd, capture_output=True)
     n = len(out.stdout) // (w * h * 3)
@@ -71,7 +140,6 @@ def load_frames(source: Union[str, Path, np.ndarray], height: int, width: int, f
     """Frame sequence for video conditioning (utils.py:578-613, which decodes with cv2 and resizes every decoded uint8
     frame with INTER_AREA): a video file (through ffmpeg, where installed), a directory of images (sorted), or an
     (F,H,W,3) uint8/float array or .npy file.  (F,H,W,3) in [0,1]."""
-    from PIL import Image
     if isinstance(source, (str, Path)) and Path(source).is_file() and Path(source).suffix.lower() in VIDEO_SUFFIXES:
         source = decode_video_ffmpeg(source, frame_cap)
     if isinstance(source, (str, Path)) and Path(source).is_dir():
@@ -83,26 +151,24 @@ def load_frames(source: Union[str, Path, np.ndarray], height: int, width: int, f
     if arr.ndim != 4 or arr.shape[-1] != 3:
         raise ValueError(f"expected (F,H,W,3) frames, got {arr.shape}")
     arr = arr[:frame_cap]
+    if arr.shape[1:3] != (height, width):
+        arr = resize_area(arr, height, width)              # on the decoded uint8 frames, as utils.py:597-598
     if arr.dtype == np.uint8:
         arr = arr.astype(np.float32) / 255.0
-    if arr.shape[1:3] != (height, width):
-        arr = np.stack([np.asarray(Image.fromarray((f * 255).round().astype(np.uint8)).resize((width, height), Image.Resampling.BOX)).astype(np.float32) / 255.0
-                        for f in arr], 0)              # INTER_AREA analogue
     return arr.astype(np.float32)
 
 
 def resize_conditioning(frames01: np.ndarray, height: int, width: int, is_video: bool) -> torch.Tensor:
     """(F,H,W,3) in [0,1] -> (1,3,F,height,width) in [-1,1], resized the way the reference prepares an already
     decoded source of another size: images through uint8 + LANCZOS (prepare_image_for_encoding, utils.py:643-661:
-    `(image*255).astype(uint8)`, i.e. truncation), video frames with an area filter (prepare_video_for_encoding,
-    utils.py:699-705; cv2.INTER_AREA there, PIL's BOX filter here - cv2 is not installed in this image)."""
-    from PIL import Image
-    out = []
-    for f in frames01:
-        u8 = (f * 255).astype(np.uint8)
-        flt = Image.Resampling.BOX if is_video else Image.Resampling.LANCZOS
-        out.append(np.asarray(Image.fromarray(u8).resize((width, height), flt)).astype(np.float32) / 255.0)
-    arr = np.stack(out, 0)
+    `(image*255).astype(uint8)`, i.e. truncation), video frames with cv2.INTER_AREA on the float frames
+    (prepare_video_for_encoding, utils.py:699-705; resize_area above)."""
+    if is_video:
+        arr = resize_area(np.asarray(frames01, np.float32), height, width)
+    else:
+        from PIL import Image
+        arr = np.stack([np.asarray(Image.fromarray((f * 255).astype(np.uint8)).resize((width, height), Image.Resampling.LANCZOS)).astype(np.float32) / 255.0
+                        for f in frames01], 0)
     t = torch.from_numpy(np.ascontiguousarray(arr)).permute(3, 0, 1, 2)[None]
     return t * 2.0 - 1.0
 

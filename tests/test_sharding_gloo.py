@@ -103,3 +103,19 @@ def test_bench_gpus_n_without_launcher_never_reports_one_gpu():
         pytest.skip("8 GPUs visible: the launcher would really start the bench")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in r.stderr
+
+
+def test_bench_self_launch_fails_fast_when_a_rank_dies():
+    """The self-launcher polls every child: ranks that die at start-up (no GPU in this container: set_device raises) end
+    the run at once with a non-zero code and no result line, instead of leaving the others to the process-group timeout."""
+    import subprocess, sys, time
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the rehearsal ranks would really run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["LTXK_BENCH_REHEARSAL"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '"metric"' not in r.stdout and "a rank failed" in r.stderr
+    assert time.time() - t0 < 120

@@ -95,3 +95,24 @@ def test_cfg_pair_hip_two_gpus_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (one rank per GPU over RCCL)")
     _run("nccl", False)
+
+
+def test_bench_n2_code_path_rehearsal():
+    """bench.py's N>1 code - the self-launcher, init_process_group, per-pair new_group, the weak-scaling timing with its
+    barriers / MAX over ranks and the cfgpair leg - executed as a fresh child process with two ranks sharing this box's
+    one GPU over gloo (LTXK_BENCH_REHEARSAL=1; the numbers of such a run are not measurements).  On the driver's 8-GPU node
+    the same code runs over RCCL; this test keeps it from being executed there for the first time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["LTXK_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
+                        "--no-vae", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert res["cfgpair"].get("finite") is True and res["cfgpair"]["pairs"] == 1, res["cfgpair"]

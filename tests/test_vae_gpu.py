@@ -49,7 +49,7 @@ def test_conv3d(dev, cin, cout, causal, reflect, shape):
     parity.auto(rel_l2(cf(out_r), O.BF16.r(ref + res.float())), 3e-3)
 
 
-@pytest.mark.parametrize("C", [128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("C", [64, 128, 256, 512, 1024, 2048])      # 64: eight lanes per row, two rows per DPP row (common.h group_sum)
 @pytest.mark.parametrize("mod", [False, True])
 def test_pixelnorm_act(dev, C, mod):
     from mlx_video_amd import video_vae as V
