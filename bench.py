@@ -96,6 +96,47 @@ def source_sha() -> str:
     return h.hexdigest()[:16]
 
 
+_PMC_CACHE = {}
+
+
+def pmc_entries():
+    """Newest profiles/r*_pmc_traffic.json measured on the kernel sources that are loaded now (source_sha match), or {}: the
+    separate rocprofv3 --pmc passes of scripts/pmc_families.py (FETCH_SIZE / WRITE_SIZE gfx950-corrected, MFMA-busy, clock)."""
+    if "v" not in _PMC_CACHE:
+        import glob
+        _PMC_CACHE["v"] = ({}, None)
+        sha = source_sha()
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                pm = json.load(open(pf))
+            except (OSError, ValueError):
+                continue
+            if pm.get("source_sha") == sha:
+                _PMC_CACHE["v"] = (pm.get("kernels", {}), os.path.basename(pf))
+                break
+    return _PMC_CACHE["v"]
+
+
+def family_traffic(family: str, prefer: str):
+    """`roofline.traffic` of one kernel family: the PMC record of its launch shape `prefer` (per launch, like `achieved`), plus
+    MFMA-busy / clock / traffic ratio of every profiled shape of the family.  None when no PMC file matches the sources."""
+    kern, fname = pmc_entries()
+    fam = {n: v for n, v in kern.items() if v.get("family") == family and "bytes_per_launch" in v}
+    if not fam:
+        return None
+    name = prefer if prefer in fam else sorted(fam)[0]
+    k = fam[name]
+    t = {"bytes_per_launch": k["bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
+         "traffic_over_algorithmic": k["bytes_per_launch"] / k["algorithmic_bytes"], "kernel": f"{k.get('kernel')} [{k.get('shape')}]",
+         "source_sha": source_sha(), "source": f"profiles/{fname} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 / WRITE_SIZE, separate passes)"}
+    by = {n: v for n, v in fam.items() if "mfma_busy_frac_of_simd_cycles" in v}
+    if by:
+        t["mfma_busy_frac_by_shape"] = {n: round(v["mfma_busy_frac_of_simd_cycles"], 3) for n, v in by.items()}
+        t["clock_GHz_by_shape"] = {n: round(v["clock_GHz_profiled"], 2) for n, v in by.items()}
+        t["traffic_over_algorithmic_by_shape"] = {n: round(v["bytes_per_launch"] / v["algorithmic_bytes"], 2) for n, v in fam.items()}
+    return t
+
+
 def cpu_baseline_block(threads: int):
     """CPU baseline (kind "port"): the oracle's transformer block, fp32, at the bench shape
     (B=2 CFG pair, N=1280, S=1024, D=4096) — REPS of the 48 blocks (about 10 s of host work), scaled to steps/s."""
@@ -483,26 +524,9 @@ def main() -> None:
     if "gemm_bf16" in fams:
         gm = fams["gemm_bf16"]
         ach = gm["flops"] / (gm["ms"] * 1e-3) / 1e12
-        traffic = None
-        try:   # L2->fabric bytes of the dominant GEMM launch (FF1) from separate --pmc passes (gfx950-corrected);
-            # quoted only while the kernel sources still hash to what the passes were measured on (newest round first)
-            import glob
-            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-                pm = json.load(open(pf))
-                if pm.get("source_sha") != source_sha():
-                    continue
-                k = next(v for n, v in pm["kernels"].items() if "FF1" in n)
-                traffic = {"bytes_per_launch": k["read_bytes_corrected"] + k["write_bytes"], "algorithmic_bytes": k["algorithmic_bytes"],
-                           "kernel": "FF1 GEMM M=2560 N=16384 K=4096", "source_sha": pm["source_sha"],
-                           "source": f"profiles/{os.path.basename(pf)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
-                           # same passes: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) and the clock held, per launch shape
-                           "mfma_busy_frac_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["mfma_busy_frac_of_simd_cycles"], 3)
-                                                       for n, v in pm["kernels"].items() if "mfma_busy_frac_of_simd_cycles" in v},
-                           "clock_GHz_by_shape": {"ff1_gelu" if "FF1" in n else n: round(v["clock_GHz_profiled"], 2)
-                                                  for n, v in pm["kernels"].items() if v.get("clock_GHz_profiled")}}
-                break
-        except Exception:
-            pass
+        # L2->fabric bytes of the dominant GEMM launch (FF1) from separate --pmc passes (gfx950-corrected); quoted only while the
+        # kernel sources still hash to what the passes were measured on
+        traffic = family_traffic("gemm_bf16", "gemm_ff1_gelu")
         rooflines["gemm_bf16"] = {"kernel": "ltxk::gemm_bf16_kernel + gemm_bf16_big_kernel (all Linear layers; algorithmic FLOPs = sum 2*M*N*K per launch)",
                                   "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
                                   "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": traffic,
@@ -518,14 +542,16 @@ def main() -> None:
         fa = fams["flash_attn"]
         ach = fa["flops"] / (fa["ms"] * 1e-3) / 1e12
         rooflines["flash_attn"] = {"kernel": "ltxk::flash_attn16_kernel (4*B*H*Tq*Tk*128 FLOP per launch)", "bound": "mfma", "achieved": ach,
-                                   "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                                   "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_DENSE_TFLOPS,
+                                   "traffic": family_traffic("flash_attn", "attn_1280x1280"),
                                    "launches": fa["launches"], "avg_ms": fa["ms"] / fa["launches"]}
         result["attention_tflops"] = ach
     for k in ("rmsnorm_modulate", "qknorm_rope"):
         if k in fams and fams[k]["ms"] > 0:
             gbs = fams[k]["bytes"] / (fams[k]["ms"] * 1e-3) / 1e9
             rooflines[k] = {"kernel": f"ltxk {k} (algorithmic bytes: read x [+ tables], write y)", "bound": "hbm", "achieved": gbs,
-                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                            "traffic": family_traffic(k, "norm_mod" if k == "rmsnorm_modulate" else "qknorm_k"),
                             "launches": fams[k]["launches"], "avg_ms": fams[k]["ms"] / fams[k]["launches"]}
             result[f"{k}_GBs"] = gbs
     if "gemm_bf16" in rooflines:
@@ -554,7 +580,7 @@ def main() -> None:
                 result["roofline_by_family"]["conv3d_k3"] = {
                     "kernel": "ltxk::conv3d_k3_kw_kernel + conv3d_k3_kernel (2*27*Cin*Cout*voxels FLOP per launch)", "bound": "mfma",
                     "achieved": vres["vae_conv3d_tflops"], "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                    "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": None,
+                    "frac": vres["vae_conv3d_tflops"] / PEAK_BF16_DENSE_TFLOPS, "traffic": family_traffic("conv3d_k3", "conv128"),
                     "launches": vres.get("vae_conv3d_launches"),
                     "avg_ms": (vres["vae_kernel_breakdown_ms"]["conv3d_k3"] / vres["vae_conv3d_launches"]
                                if vres.get("vae_conv3d_launches") and "vae_kernel_breakdown_ms" in vres else None)}

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LTXK_VERSION 300
+#define LTXK_VERSION 400
 
 #define LTXK_OK 0
 #define LTXK_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
@@ -82,6 +82,13 @@ typedef struct ltxk_gemm_args {
    * utils.py:398-400; q/k RMSNorm, attention.py:129-131) take its row statistic without re-reading the row.   */
   float* sumsq;
   int32_t sumsq_ld;
+  /* Optional caller-owned scratch (16-byte aligned, fp32), reused by every call on the stream.  With it, a launch whose
+   * row count gives the chip too few workgroups to stream the weight panel (small M: low-resolution / distilled stage-1
+   * steps, ltx.py:459-506 at config 1's geometry) runs as split-K: every K slice parks its fp32 accumulator tile here
+   * (slices x M x N x 4 bytes; fewer slices if the scratch is smaller) and a second launch sums the slices in slice order
+   * and applies the epilogue - deterministic, one rounding of the fp32 sum.  NULL: never split.                        */
+  void* workspace;
+  int64_t workspace_bytes;
 } ltxk_gemm_args;
 
 int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);

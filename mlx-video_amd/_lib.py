@@ -22,6 +22,7 @@ class GemmArgs(Structure):
         ("lda", c_int32), ("ldo", c_int32), ("ldr", c_int32), ("gate_stride", c_int32),
         ("epilogue", c_int32), ("out_tokens_per_batch", c_int32), ("alpha", c_float),
         ("out2", c_void_p), ("n_split", c_int32), ("ldo2", c_int32), ("sumsq", c_void_p), ("sumsq_ld", c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 

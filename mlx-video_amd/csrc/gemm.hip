@@ -36,7 +36,6 @@ extern "C" int ltxk_diag_set_gemm_stamps(void* p) {
 
 namespace ltxk {
 
-constexpr int GEMM_BN = 256;
 
 struct GemmParams {
   const bf16* A;
@@ -57,25 +56,32 @@ struct GemmParams {
   // per-row sums of squares of the stored bf16 outputs, one fp32 per 64-column block: sumsq[m*sumsq_ld + n/64]
   float* sumsq;
   int sumsq_ld;
+  // split-K (gemm_stream_kernel): blockIdx.y = K slice; slice s covers K-steps [s*ksteps, min(K/64, (s+1)*ksteps)) and stores its
+  // fp32 accumulators to part[(s*M + m)*N + n]; splitk_epilogue_kernel sums the slices in order and applies the epilogue
+  float* part;
+  int ksteps;
 };
 
-template <int TT, int EPI, bool TRANS>
-__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, int wave, int lane) {
-  using G = GemmGeom<TT, 4>;
+// NT = 16-column MFMA tiles per wave: 4 -> 256-column workgroup tiles (64 per wave), 2 -> 128-column ones (32 per wave).
+template <int TT, int NT, int EPI, bool TRANS>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m0, int n0, int kbase, int nk, int wave, int lane) {
+  using G = GemmGeom<TT, 4, NT>;
   constexpr int GEMM_W_STAGE_BYTES = G::W_STAGE_BYTES;
+  constexpr int WPW = G::W_PER_WAVE;          // W pieces per wave per stage (4 / 2)
+  constexpr int WC = 16 * NT;                 // columns per wave
   const int wm = wave >> 2, wn = wave & 3;
 
   // ---- loader: per-lane source pointers (row clamped, 16-byte chunk pre-swizzled) ----
   const int lrow = lane >> 3;
   const int chunk = (lane & 7) ^ lrow;
-  const bf16* wptr[4];
+  const bf16* wptr[WPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = n0 + (wave * 4 + i) * 8 + lrow;
+  for (int i = 0; i < WPW; ++i) {
+    int r = n0 + (wave * WPW + i) * 8 + lrow;
     r = r < p.N ? r : p.N - 1;
     wptr[i] = p.W + (size_t)r * p.K + chunk * 8;
   }
-  // Every wave issues exactly 4 W pieces + MAXA A pieces per stage, so one constant vmcnt retires a
+  // Every wave issues exactly WPW W pieces + MAXA A pieces per stage, so one constant vmcnt retires a
   // stage.  A_PIECES is not a multiple of 8 (20 at BM=160): waves past A_REM own one piece fewer and
   // re-issue their last piece (same source, same LDS bytes: benign) to keep the count uniform.
   const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
@@ -90,29 +96,28 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     aptr[i] = p.A + (size_t)r * p.lda + chunk * 8;
     adst[i] = GEMM_W_STAGE_BYTES + (pi < G::A_PIECES ? pi : G::A_PIECES - 1) * 1024;
   }
-  constexpr int PER_STAGE = 4 + G::MAXA;
+  constexpr int PER_STAGE = WPW + G::MAXA;
   static_assert(PER_STAGE <= 7, "vmcnt immediates below assume <= 7 pieces per stage");
 
-  // i-th LDS-DMA piece of this wave for K-step kt into ring slot s (pieces 0..3 = W, 4.. = A)
+  // i-th LDS-DMA piece of this wave for K-step kt (of this launch slice) into ring slot s (pieces 0..WPW-1 = W, then A)
   auto issue_piece = [&](int i, int kt, int s) __attribute__((always_inline)) {
     char* base = smem + s * G::STAGE_BYTES;
-    const int ko = kt * GEMM_BK;
-    if (i < 4) {
-      glds16(wptr[i] + ko, base + (wave * 4 + i) * 1024);
+    const int ko = (kbase + kt) * GEMM_BK;
+    if (i < WPW) {
+      glds16(wptr[i < WPW ? i : 0] + ko, base + (wave * WPW + i) * 1024);
     } else if (i < PER_STAGE) {
-      glds16(aptr[i - 4 < G::MAXA ? i - 4 : 0] + ko, base + adst[i - 4 < G::MAXA ? i - 4 : 0]);
+      glds16(aptr[i - WPW < G::MAXA ? i - WPW : 0] + ko, base + adst[i - WPW < G::MAXA ? i - WPW : 0]);
     }
   };
 
   constexpr bool HAS_RES = !TRANS && (EPI == LTXK_EPI_BIAS_GATE_RES || EPI == LTXK_EPI_BIAS_RES || EPI == LTXK_EPI_SCALE_RES);
   constexpr bool HAS_GATE = !TRANS && EPI == LTXK_EPI_BIAS_GATE_RES;
-  f32x4 acc[TT][4];
+  f32x4 acc[TT][NT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / GEMM_BK;
   LTXK_STAMP(0);
   // Epilogue operands (bias, residual tile, gate rows) are requested up front and arrive under the main loop instead
   // of as a dependent-load chain (gate_row -> gate -> arithmetic) and a 21 MB residual burst when the loop ends.  They
@@ -134,8 +139,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, 0, 0);
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, nk > 1 ? 1 : 0, 1);
-  bf16x4 rres[HAS_RES ? TT : 1][4], bpre[4], gpre[HAS_GATE ? TT : 1][4];
-  bf16 bpre_t[4];
+  bf16x4 rres[HAS_RES ? TT : 1][NT], bpre[NT], gpre[HAS_GATE ? TT : 1][NT];
+  bf16 bpre_t[NT];
   // The residual tile (21 MB per launch over the chip) is NOT requested here: read as one burst in the prologue it holds
   // up the first stages' arrival by ~4 us (the fabric serves it at ~5 TB/s; in-kernel stamps).  It trickles in during
   // K-steps 2 .. 1+TT, one 16-row band (4 loads per lane) per step; bands a short K (a LoRA merge: 1-2 steps) never
@@ -149,28 +154,28 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
       m = m < p.M ? m : p.M - 1;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        int n = n0 + wn * 64 + nt * 16 + nq;
+      for (int nt = 0; nt < NT; ++nt) {
+        int n = n0 + wn * WC + nt * 16 + nq;
         n = n < p.N ? n : p.N - 4;
         rres[tt][nt] = LTXK_VLOAD(bf16x4, p.resid + (size_t)m * p.ldr + n);
       }
     }
   };
-  constexpr int NB = 4;                                           // bias loads per lane, issued behind stage 1
-  constexpr int NX2 = HAS_GATE ? TT * 4 : 0;                      // gate values, issued after the first barrier
+  constexpr int NB = NT;                                          // bias loads per lane, issued behind stage 1
+  constexpr int NX2 = HAS_GATE ? TT * NT : 0;                     // gate values, issued after the first barrier
   {
     const int nq = (lane >> 4) * 4;
     if constexpr (TRANS) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+      for (int nt = 0; nt < NT; ++nt) {
+        int n = n0 + wn * WC + nt * 16 + (lane & 15);
         n = n < p.N ? n : p.N - 1;
         bpre_t[nt] = LTXK_VLOAD(bf16, p.bias ? p.bias + n : p.W);
       }
     } else {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        int n = n0 + wn * 64 + nt * 16 + nq;
+      for (int nt = 0; nt < NT; ++nt) {
+        int n = n0 + wn * WC + nt * 16 + nq;
         n = n < p.N ? n : p.N - 4;
         bpre[nt] = LTXK_VLOAD(bf16x4, p.bias ? p.bias + n : p.W);
       }
@@ -183,8 +188,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
       for (int tt = 0; tt < TT; ++tt) {
         const int gr = p.gate_row ? grow[tt] : 0;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          int n = n0 + wn * 64 + nt * 16 + nq;
+        for (int nt = 0; nt < NT; ++nt) {
+          int n = n0 + wn * WC + nt * 16 + nq;
           n = n < p.N ? n : p.N - 4;
           gpre[tt][nt] = LTXK_VLOAD(bf16x4, p.gate + (size_t)gr * p.gate_stride + n);
         }
@@ -210,7 +215,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     } else if constexpr (KC == 1) {
       wait_keep_and_barrier<PER_STAGE + NB + NX2>();
     } else if constexpr (HAS_RES && KC >= 3 && KC < 3 + TT) {
-      wait_keep_and_barrier<PER_STAGE + 4>();
+      wait_keep_and_barrier<PER_STAGE + NT>();
     } else if constexpr (KC == -3) {
       wait_keep_and_barrier<0>();                                   // last K-step: nothing younger than its own stage is in flight
     } else {
@@ -229,7 +234,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     if constexpr (TT >= 2) {
       pipe.step(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, issue);
     } else {
-      mma_stage_pipelined<TT, 4, TRANS>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, issue);
+      mma_stage_pipelined<TT, 4, TRANS, NT>(smem + s * G::STAGE_BYTES, wm, wn, lane, acc, issue);
     }
     s = s + 1 == 3 ? 0 : s + 1;
   };
@@ -250,12 +255,12 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
   if constexpr (TT >= 2) {
 #if LTXK_STAGGER
     if (wave >= 4) {                  // SIMD partners of waves 0-3 run half a K-step out of phase
-      MmaPipe<TT, 4, TRANS, TT> pipe;
+      MmaPipe<TT, 4, TRANS, TT, NT> pipe;
       kloop(pipe);
     } else
 #endif
     {
-      MmaPipe<TT, 4, TRANS, (LTXK_DEFER_GROUPS <= TT ? LTXK_DEFER_GROUPS : TT)> pipe;
+      MmaPipe<TT, 4, TRANS, (LTXK_DEFER_GROUPS <= TT ? LTXK_DEFER_GROUPS : TT), NT> pipe;
       kloop(pipe);
     }
   } else {
@@ -268,16 +273,16 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
   // in flight, i.e. a LoRA merge that raced its first stage.
   if constexpr (TRANS) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre_t[nt]));
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bpre_t[nt]));
   } else {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bpre[nt]));
+    for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bpre[nt]));
   }
   if constexpr (HAS_GATE) {
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(gpre[tt][nt]));
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(gpre[tt][nt]));
   }
   if constexpr (HAS_RES) {
     if (nk < 2 + TT) {                 // short K: the bands whose step never ran
@@ -293,20 +298,27 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
   // ---- epilogue ----
   if constexpr (!TRANS) {
     // acc[tt][nt][j]: token = lane&15, n = 4*(lane>>4) + j.  Written directly that is 16 rows x 32 bytes per store
-    // instruction; with p.wide each wave instead transposes its (16*TT x 64) block through a private LDS image
-    // (128-byte rows, 16-byte chunks XOR-swizzled by row) and stores 8 whole 128-byte lines per instruction.
+    // instruction; with p.wide each wave instead transposes its (16*TT x WC) block through a private LDS image
+    // (rows of WC*2 bytes, 16-byte chunks XOR-swizzled by row) and stores whole rows of it per instruction.
+    constexpr int RB = WC * 2, CPR = RB / 16;       // staged row bytes (128 / 64), 16-byte chunks per row (8 / 4)
     const int nq = (lane >> 4) * 4;
-    char* stg = smem + wave * (TT * 16 * 128);
+    char* stg = smem + wave * (TT * 16 * RB);
     const bool want_ss = p.sumsq != nullptr;
-    if (p.wide) __syncthreads();                   // every wave has read its last fragments from the ring
+    // NT == 2: a 64-column block of the row statistic spans the waves wn = 2c (columns 0-31) and 2c+1 (32-63).  The even wave
+    // hands its lane-wise partial sums through LDS and the odd wave continues them with its own 8 values per lane: the same
+    // 16 sequential additions per lane, then the same two exchanges, as one wave of the 256-column tile - the same bits.
+    const bool pair_hi = NT == 2 && (wn & 1);
+    float* xss = (float*)(smem + 8 * TT * 16 * RB) + ((wm * 2 + (wn >> 1)) * TT) * 64;
+    bf16x4 okeep[NT == 2 ? TT : 1][NT];
+    if (p.wide || (NT == 2 && want_ss)) __syncthreads();                   // every wave has read its last fragments from the ring
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
       if (m >= p.M) continue;
       float ss = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + nq;
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wn * WC + nt * 16 + nq;
         if (n >= p.N) continue;
         float y[4];
         if (p.bias) {
@@ -341,36 +353,69 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
         if (want_ss) {                  // (uniform branch: the row statistic costs ~3 VALU per element, a quarter of a GELU epilogue)
+          if constexpr (NT == 2) {
+            if (pair_hi) okeep[tt][nt] = o;
+          }
+          if (!pair_hi) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float f = (float)o[j];
-            ss += f * f;
+            for (int j = 0; j < 4; ++j) {
+              const float f = (float)o[j];
+              ss += f * f;
+            }
           }
         }
         if (p.wide) {
           const int r = tt * 16 + (lane & 15), cg = lane >> 4;
-          *(bf16x4*)(stg + r * 128 + (((nt * 2 + (cg >> 1)) ^ (r & 7)) << 4) + (cg & 1) * 8) = o;
+          *(bf16x4*)(stg + r * RB + (((nt * 2 + (cg >> 1)) ^ (r & (CPR - 1))) << 4) + (cg & 1) * 8) = o;
         } else {
           *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
         }
       }
       if (want_ss) {
-        // the wave's 64 columns of row m: 16 values per lane, then the four lanes sharing (lane & 15); fixed order
-        ss = lane_xor16_sum(ss);
-        ss = lane_xor32_sum(ss);
-        // (a wave whose 64-column block lies past N - the last column tile when N % 256 != 0 - has nothing to report:
-        // its slot would be the next row's first partial)
-        if (lane < 16 && n0 + wn * 64 < p.N) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
+        if constexpr (NT == 4) {
+          // the wave's 64 columns of row m: 16 values per lane, then the four lanes sharing (lane & 15); fixed order
+          ss = lane_xor16_sum(ss);
+          ss = lane_xor32_sum(ss);
+          // (a wave whose 64-column block lies past N - the last column tile when N % 256 != 0 - has nothing to report:
+          // its slot would be the next row's first partial)
+          if (lane < 16 && n0 + wn * 64 < p.N) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * 64) >> 6)] = ss;
+        } else if (!pair_hi) {
+          xss[tt * 64 + lane] = ss;
+        }
+      }
+    }
+    if constexpr (NT == 2) {
+      if (want_ss) {
+        __syncthreads();
+        if (pair_hi) {
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+            if (m >= p.M || n0 + wn * WC >= p.N) continue;
+            float ss = xss[tt * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float f = (float)okeep[tt][nt][j];
+                ss += f * f;
+              }
+            ss = lane_xor16_sum(ss);
+            ss = lane_xor32_sum(ss);
+            if (lane < 16) p.sumsq[(size_t)m * p.sumsq_ld + ((n0 + wn * WC) >> 6)] = ss;
+          }
+        }
       }
     }
     if (p.wide) {
-      const int c = lane & 7;
-      const int n = n0 + wn * 64 + c * 8;
+      constexpr int RPI = 64 / CPR;                 // rows per store instruction (8 / 16)
+      const int c = lane & (CPR - 1);
+      const int n = n0 + wn * WC + c * 8;
 #pragma unroll
-      for (int i = 0; i < TT * 2; ++i) {
-        const int r = i * 8 + (lane >> 3);
+      for (int i = 0; i < TT * 16 / RPI; ++i) {
+        const int r = i * RPI + lane / CPR;
         const int m = m0 + wm * TT * 16 + r;
-        const bf16x8 v = *(const bf16x8*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        const bf16x8 v = *(const bf16x8*)(stg + r * RB + ((c ^ (r & (CPR - 1))) << 4));
         if (m < p.M && n < p.N) *(bf16x8*)(p.out + (size_t)m * p.ldo + n) = v;
       }
     }
@@ -382,8 +427,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
     const int tld = p.n_split ? p.ldo2 : p.ldo;
     const int tN = p.N - p.n_split;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * WC + nt * 16 + (lane & 15);
       if (n >= p.N) continue;
       const float b = p.bias ? (float)bpre_t[nt] : 0.f;
 #pragma unroll
@@ -414,9 +459,9 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, char* smem, int m
 
 // MODE 0: every tile row-major with epilogue EPI; 1: every tile transposed (V^T); 2: split output - tiles with
 // n0 < n_split row-major (EPI), the rest transposed (one launch for q|k|v, or for the text k|v pair)
-template <int TT, int EPI, int MODE>
+template <int TT, int NT, int EPI, int MODE>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
-  using G = GemmGeom<TT, 4>;
+  using G = GemmGeom<TT, 4, NT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   LTXK_STAMP(4);
   const int tid = threadIdx.x;
@@ -424,14 +469,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int rt, ct;
   map_tile(blockIdx.x, p.RT, p.CT, rt, ct);
-  const int m0 = rt * G::BM, n0 = ct * GEMM_BN;
+  const int m0 = rt * G::BM, n0 = ct * G::BN;
+  const int kbase = 0, nk = p.K / GEMM_BK;
   if constexpr (MODE == 0) {
-    gemm_tile<TT, EPI, false>(p, smem, m0, n0, wave, lane);
+    gemm_tile<TT, NT, EPI, false>(p, smem, m0, n0, kbase, nk, wave, lane);
   } else if constexpr (MODE == 1) {
-    gemm_tile<TT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+    gemm_tile<TT, NT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, kbase, nk, wave, lane);
   } else {
-    if (n0 < p.n_split) gemm_tile<TT, EPI, false>(p, smem, m0, n0, wave, lane);
-    else gemm_tile<TT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, wave, lane);
+    if (n0 < p.n_split) gemm_tile<TT, NT, EPI, false>(p, smem, m0, n0, kbase, nk, wave, lane);
+    else gemm_tile<TT, NT, LTXK_EPI_BIAS, true>(p, smem, m0, n0, kbase, nk, wave, lane);
   }
 #ifdef LTXK_DIAG
   __syncthreads();
@@ -447,11 +493,199 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(GemmParams p) {
 #endif
 }
 
+// One K slice of a small-M (weight-streaming) launch on the 128-column tile: nothing but the main loop and the fp32 tile store,
+// with the LDS ring as deep as the CU's 160 KiB allow (6 stages of 24.5 KiB at 64 rows against the 3 of gemm_tile): such a
+// launch is a stream of weight bytes, a workgroup's rate is (stages in flight) x (stage bytes) / (memory latency), and with three
+// stages a 64 x 128 tile pulled ~50 GB/s - 160 of them 1 TB/s of a 32-MB panel (profiles/r04_small_m_ab.log).  Every wave
+// issues the same number of LDS-DMA pieces per K-step (a clamped re-load of the last stage into a free slot once the real
+// ones run out), so one constant counted vmcnt retires a stage.
+template <int TT> struct StreamGeom {
+  using G = GemmGeom<TT, 4, 2>;
+  static constexpr int D = (160 * 1024) / G::STAGE_BYTES < 6 ? (160 * 1024) / G::STAGE_BYTES : 6;
+  static constexpr int LDS = D * G::STAGE_BYTES;
+  static_assert(D >= 3, "ring too shallow");
+};
 
-template <int TT, int EPI, int MODE>
+template <int TT>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_stream_kernel(GemmParams p) {
+  using G = GemmGeom<TT, 4, 2>;
+  constexpr int D = StreamGeom<TT>::D, NT = 2, WPW = G::W_PER_WAVE, PER_STAGE = WPW + G::MAXA;
+  static_assert(PER_STAGE * (D - 2) <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ct = blockIdx.x % p.CT, rt = blockIdx.x / p.CT;
+  const int m0 = rt * G::BM, n0 = ct * G::BN;
+  const int nk_all = p.K / GEMM_BK;
+  const int kbase = (int)blockIdx.y * p.ksteps;
+  const int nk = nk_all - kbase < p.ksteps ? nk_all - kbase : p.ksteps;
+  const int lrow = lane >> 3, chunk = (lane & 7) ^ lrow;
+  const bf16* wptr[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    int r = n0 + (wave * WPW + i) * 8 + lrow;
+    r = r < p.N ? r : p.N - 1;
+    wptr[i] = p.W + (size_t)r * p.K + chunk * 8;
+  }
+  const int nA = G::A_BASE + (wave < G::A_REM ? 1 : 0);
+  const int a0 = wave * G::A_BASE + (wave < G::A_REM ? wave : G::A_REM);
+  const bf16* aptr[G::MAXA];
+  int adst[G::MAXA];
+#pragma unroll
+  for (int i = 0; i < G::MAXA; ++i) {
+    const int pi = nA > 0 ? a0 + (i < nA ? i : nA - 1) : G::A_PIECES - 1;
+    int r = m0 + pi * 8 + lrow;
+    r = r < p.M ? r : p.M - 1;
+    aptr[i] = p.A + (size_t)r * p.lda + chunk * 8;
+    adst[i] = G::W_STAGE_BYTES + pi * 1024;
+  }
+  auto issue_piece = [&](int i, int kt, int slot) __attribute__((always_inline)) {
+    char* base = smem + slot * G::STAGE_BYTES;
+    const int ko = (kbase + (kt < nk ? kt : nk - 1)) * GEMM_BK;
+    if (i < WPW) glds16(wptr[i < WPW ? i : 0] + ko, base + (wave * WPW + i) * 1024);
+    else if (i < PER_STAGE) glds16(aptr[i - WPW < G::MAXA ? i - WPW : 0] + ko, base + adst[i - WPW < G::MAXA ? i - WPW : 0]);
+  };
+  f32x4 acc[TT][NT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < D - 1; ++st)
+#pragma unroll
+    for (int i = 0; i < PER_STAGE; ++i) issue_piece(i, st, st);
+  auto loop = [&](auto& pipe) __attribute__((always_inline)) {
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_keep_and_barrier<PER_STAGE * (D - 2)>();            // stage kt has landed; D-2 younger stages stay in flight
+      const int pre = slot == 0 ? D - 1 : slot - 1;            // slot of stage kt + D - 1 = the one consumed in step kt - 1
+      auto issue = [&](int i) __attribute__((always_inline)) { issue_piece(i, kt + D - 1, pre); };
+      if constexpr (TT >= 2) pipe.step(smem + slot * G::STAGE_BYTES, wm, wn, lane, acc, issue);
+      else mma_stage_pipelined<TT, 4, false, NT>(smem + slot * G::STAGE_BYTES, wm, wn, lane, acc, issue);
+      slot = slot + 1 == D ? 0 : slot + 1;
+    }
+  };
+  if constexpr (TT >= 2) {
+    MmaPipe<TT, 4, false, 2, NT> pipe;
+    pipe.init();
+    loop(pipe);
+    pipe.finish(acc);
+  } else {
+    int dummy = 0;
+    loop(dummy);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the clamped re-loads must not outlive the workgroup's LDS
+  const int nq = (lane >> 4) * 4;
+  float* dst = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int m = m0 + wm * TT * 16 + tt * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + wn * 32 + nt * 16 + nq;
+      if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[tt][nt];
+    }
+  }
+}
+
+template <int TT>
+static int launch_stream(const GemmParams& p, int ksplit, hipStream_t stream) {
+  auto kern = gemm_stream_kernel<TT>;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev != attr_dev) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, StreamGeom<TT>::LDS);
+    if (e != hipSuccess) {
+      ltxk_set_error("ltxk_gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return LTXK_ELAUNCH;
+    }
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.RT * p.CT, ksplit), dim3(GEMM_THREADS), StreamGeom<TT>::LDS, stream, p);
+  LTXK_CHECK_LAUNCH("ltxk_gemm_bf16 (split-K slices)");
+  return LTXK_OK;
+}
+
+// Second launch of a split-K GEMM: sums the S fp32 slices in slice order (deterministic) and applies the epilogue of
+// gemm_tile - the same formulas and rounding points, one rounding of the fp32 sum.  One thread = 4 consecutive columns of
+// one row; a 64-column block of the row statistic is 16 consecutive lanes.  `trans` = every column transposed (V^T).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmParams p, int S, int epi, int trans) {
+  const int n4 = p.N >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < (long)p.M * n4;
+  const int m = live ? (int)(idx / n4) : 0, n = live ? (int)(idx - (long)m * n4) * 4 : 0;
+  const size_t slab = (size_t)p.M * p.N;
+  const float* src = p.part + (size_t)m * p.N + n;
+  f32x4 a = *(const f32x4*)src;
+  int sl = 1;
+  for (; sl + 4 <= S; sl += 4) {                 // four independent loads in flight, added in slice order
+    const f32x4 b0 = *(const f32x4*)(src + (size_t)sl * slab), b1 = *(const f32x4*)(src + (size_t)(sl + 1) * slab);
+    const f32x4 b2 = *(const f32x4*)(src + (size_t)(sl + 2) * slab), b3 = *(const f32x4*)(src + (size_t)(sl + 3) * slab);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = ((a[j] + b0[j]) + b1[j]) + b2[j] + b3[j];
+  }
+  for (; sl < S; ++sl) {
+    const f32x4 b = *(const f32x4*)(src + (size_t)sl * slab);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += b[j];
+  }
+  bf16x4 bias = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  if (p.bias) bias = *(const bf16x4*)(p.bias + n);
+  if (trans || (p.n_split && n >= p.n_split)) {
+    if (!live) return;
+    bf16* const tout = p.n_split ? p.out2 : p.out;
+    const int tld = p.n_split ? p.ldo2 : p.ldo, tN = p.N - p.n_split;
+    const int bidx = m / p.T, t = m - bidx * p.T;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tout[((size_t)bidx * tN + (n + j - p.n_split)) * tld + t] = (bf16)(a[j] + (float)bias[j]);
+    return;
+  }
+  float y[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = p.bias ? rbf(a[j] + (float)bias[j]) : rbf(a[j]);
+  if (epi == LTXK_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = gelu_tanh_f(y[j]);
+  } else if (epi == LTXK_EPI_BIAS_SILU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = silu_f(y[j]);
+  } else if (epi == LTXK_EPI_BIAS_GATE_RES || epi == LTXK_EPI_BIAS_RES || epi == LTXK_EPI_SCALE_RES) {
+    const bf16x4 r = *(const bf16x4*)(p.resid + (size_t)m * p.ldr + n);
+    if (epi == LTXK_EPI_BIAS_GATE_RES) {
+      const bf16x4 g = *(const bf16x4*)(p.gate + (size_t)(p.gate_row ? p.gate_row[m] : 0) * p.gate_stride + n);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(y[j] * (float)g[j]);
+    } else if (epi == LTXK_EPI_BIAS_RES) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + y[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (float)r[j] + rbf(p.alpha * a[j]);
+    }
+  }
+  bf16x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (bf16)y[j];
+  if (live) *(bf16x4*)(p.out + (size_t)m * p.ldo + n) = o;
+  if (p.sumsq) {                                   // (N % 64 == 0: a 64-column block = 16 aligned consecutive lanes of one row)
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float f = (float)o[j];
+      ss += f * f;
+    }
+    ss = group_sum<16>(ss);
+    if (live && (threadIdx.x & 15) == 0) p.sumsq[(size_t)m * p.sumsq_ld + (n >> 6)] = ss;
+  }
+}
+
+template <int TT, int NT, int EPI, int MODE>
 static int launch(const GemmParams& p, hipStream_t stream) {
-  using G = GemmGeom<TT, 4>;
-  auto kern = gemm_bf16_kernel<TT, EPI, MODE>;
+  using G = GemmGeom<TT, 4, NT>;
+  auto kern = gemm_bf16_kernel<TT, NT, EPI, MODE>;
   static thread_local int attr_dev = -1;
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -469,41 +703,68 @@ static int launch(const GemmParams& p, hipStream_t stream) {
   return LTXK_OK;
 }
 
-template <int TT>
+template <int TT, int NT>
 static int dispatch_epi(const GemmParams& p, int epi, bool trans, hipStream_t stream) {
-  if (p.n_split) return launch<TT, LTXK_EPI_BIAS, 2>(p, stream);
-  if (trans) return launch<TT, LTXK_EPI_BIAS, 1>(p, stream);
+  if (p.n_split) return launch<TT, NT, LTXK_EPI_BIAS, 2>(p, stream);
+  if (trans) return launch<TT, NT, LTXK_EPI_BIAS, 1>(p, stream);
   switch (epi) {
-    case LTXK_EPI_BIAS: return launch<TT, LTXK_EPI_BIAS, 0>(p, stream);
-    case LTXK_EPI_BIAS_GELU: return launch<TT, LTXK_EPI_BIAS_GELU, 0>(p, stream);
-    case LTXK_EPI_BIAS_SILU: return launch<TT, LTXK_EPI_BIAS_SILU, 0>(p, stream);
-    case LTXK_EPI_BIAS_GATE_RES: return launch<TT, LTXK_EPI_BIAS_GATE_RES, 0>(p, stream);
-    case LTXK_EPI_BIAS_RES: return launch<TT, LTXK_EPI_BIAS_RES, 0>(p, stream);
-    case LTXK_EPI_SCALE_RES: return launch<TT, LTXK_EPI_SCALE_RES, 0>(p, stream);
+    case LTXK_EPI_BIAS: return launch<TT, NT, LTXK_EPI_BIAS, 0>(p, stream);
+    case LTXK_EPI_BIAS_GELU: return launch<TT, NT, LTXK_EPI_BIAS_GELU, 0>(p, stream);
+    case LTXK_EPI_BIAS_SILU: return launch<TT, NT, LTXK_EPI_BIAS_SILU, 0>(p, stream);
+    case LTXK_EPI_BIAS_GATE_RES: return launch<TT, NT, LTXK_EPI_BIAS_GATE_RES, 0>(p, stream);
+    case LTXK_EPI_BIAS_RES: return launch<TT, NT, LTXK_EPI_BIAS_RES, 0>(p, stream);
+    case LTXK_EPI_SCALE_RES: return launch<TT, NT, LTXK_EPI_SCALE_RES, 0>(p, stream);
   }
   ltxk_set_error("ltxk_gemm_bf16: unknown epilogue %d", epi);
   return LTXK_EINVAL;
 }
 
-// Row-tile height: minimise (rounds over 256 CUs) x (tile rows + fixed per-tile overhead).
+template <int NT>
+static int dispatch_tt(const GemmParams& p, int tt, int epi, bool trans, hipStream_t st) {
+  switch (tt) {
+    case 5: return dispatch_epi<5, NT>(p, epi, trans, st);
+    case 4: return dispatch_epi<4, NT>(p, epi, trans, st);
+    case 3: return dispatch_epi<3, NT>(p, epi, trans, st);
+    case 2: return dispatch_epi<2, NT>(p, epi, trans, st);
+    default: return dispatch_epi<1, NT>(p, epi, trans, st);
+  }
+}
+
+// split-K slices on the 128-column tile (the weight-streaming form for small M): fp32 partial tiles, then the epilogue launch
+static int launch_partial(const GemmParams& p, int tt, int ksplit, hipStream_t st) {
+  switch (tt) {
+    case 5: return launch_stream<5>(p, ksplit, st);
+    case 4: return launch_stream<4>(p, ksplit, st);
+    case 3: return launch_stream<3>(p, ksplit, st);
+    case 2: return launch_stream<2>(p, ksplit, st);
+    default: return launch_stream<1>(p, ksplit, st);
+  }
+}
+
+// Tile choice: row-tile height TT (32*TT rows) and column width (256 or 128), minimising
+//   (rounds over 256 CUs) x (cost of one tile) ,  cost = rows + fixed per-tile overhead for the 256-column tile,
+//   W128 x that for the 128-column one (half the MFMAs per K-step, but 0.7 instead of 0.45 fragment reads and 1.6x the
+//   LDS-DMA pieces per MFMA: measured, profiles/r04_gemm_128col_ab.log).
 // (Round 3, tried and removed: "whole rounds first" - the rows of the whole 256-CU rounds as 160-row tiles, the remaining rows
 // as a second launch at their own best height.  The model below prices it 5-9 % cheaper at M=3328 / 5184 / 6656, N=4096;
 // measured -0.5...-2.3 % at M=3328 / 6656 and +3...4 % at M=5184 (profiles/r03_gemm_rounds_ab.log): a part-filled last round
 // costs less than the model's whole round - the busy CUs run at a higher clock - and the second launch pays its own fill,
 // epilogue and boundary.)
-static int pick_tt(int M, int N) {
-  const int cand[5] = {5, 4, 3, 2, 1};
-  const int CT = (N + GEMM_BN - 1) / GEMM_BN;
-  int best = 5;
-  long best_cost = -1;
-  for (int i = 0; i < 5; ++i) {
-    const int bm = 32 * cand[i];
-    const long RT = (M + bm - 1) / bm;
-    const long rounds = (RT * CT + 255) / 256;
-    const long cost = rounds * (bm + 48);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      best = cand[i];
+struct TileChoice { int tt, nt; long cost; };
+static long tile_cost(int M, int N, int tt, int nt) {
+  const int bm = 32 * tt, bn = 64 * nt;
+  const long RT = (M + bm - 1) / bm, CT = (N + bn - 1) / bn;
+  const long rounds = (RT * CT + 255) / 256;
+  const long per_tile = nt == 4 ? 100L * (bm + 48) : (long)LTXK_AB_INT("LTXK_GEMM_W128", 70) * (bm + 40);
+  return rounds * per_tile;
+}
+static TileChoice pick_tile(int M, int N, int nt_force) {
+  TileChoice best = {5, 4, -1};
+  for (int nt = 4; nt >= 2; nt -= 2) {
+    if (nt_force && nt != nt_force) continue;
+    for (int tt = 5; tt >= 1; --tt) {
+      const long c = tile_cost(M, N, tt, nt);
+      if (best.cost < 0 || c < best.cost) best = {tt, nt, c};
     }
   }
   return best;
@@ -656,11 +917,14 @@ __device__ __forceinline__ void gemm_big_tile(const GemmParams& p, char* smem, i
     for (int j = 8 - HB; j < 8; ++j) mma(acc[i][j], wf[j], af[i]);
   // hipcc does not see the asm MFMAs as matrix instructions and pads no hazard: let the last ones retire before the
   // accumulators are read (the operands tie the wait to the registers written last)
-  constexpr int L1 = RB - 1, L2 = RB - 2, L3 = RB - 3;
-  asm volatile("s_nop 15\n\ts_nop 15"
-               : "+v"(acc[L2][4]), "+v"(acc[L2][5]), "+v"(acc[L2][6]), "+v"(acc[L2][7]), "+v"(acc[L1][0]), "+v"(acc[L1][1]),
-                 "+v"(acc[L1][2]), "+v"(acc[L1][3]), "+v"(acc[L1][4]), "+v"(acc[L1][5]), "+v"(acc[L1][6]), "+v"(acc[L1][7]),
-                 "+v"(acc[0][7]), "+v"(acc[1][7]), "+v"(acc[L3][7]), "+v"(acc[0][6]), "+v"(acc[1][6]), "+v"(acc[L3][6]), "+v"(acc[0][5]), "+v"(acc[1][5]), "+v"(acc[L3][5]));
+  // (every accumulator the last MFMA rows wrote appears exactly once as an operand: the last two rows whole, the held-back
+  // columns of every row - an lvalue repeated among the read-write operands of one asm statement is unspecified)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (i >= RB - 2 || j >= 8 - HB) asm volatile("" : "+v"(acc[i][j]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if constexpr (!TRANS) {
@@ -839,7 +1103,7 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   const bool trans = a->out_tokens_per_batch > 0 && !split;
   if (split) {
     LTXK_CHECK_ARG(a->epilogue == LTXK_EPI_BIAS, "ltxk_gemm_bf16: split output supports EPI_BIAS only");
-    LTXK_CHECK_ARG(a->n_split % GEMM_BN == 0 && a->n_split < a->N, "ltxk_gemm_bf16: n_split=%d must be a multiple of %d below N=%d", a->n_split, GEMM_BN, a->N);
+    LTXK_CHECK_ARG(a->n_split % 256 == 0 && a->n_split < a->N, "ltxk_gemm_bf16: n_split=%d must be a multiple of 256 below N=%d", a->n_split, a->N);
     LTXK_CHECK_ARG(a->out2 != nullptr && ((uintptr_t)a->out2 & 7) == 0, "ltxk_gemm_bf16: split output needs an 8-byte aligned out2");
     LTXK_CHECK_ARG(a->out_tokens_per_batch > 0 && a->M % a->out_tokens_per_batch == 0, "ltxk_gemm_bf16: split output needs out_tokens_per_batch dividing M=%d", a->M);
     LTXK_CHECK_ARG(a->ldo2 >= a->out_tokens_per_batch && a->ldo2 % 4 == 0, "ltxk_gemm_bf16: transposed ldo2=%d", a->ldo2);
@@ -874,16 +1138,21 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
   // them behind it measured 2 % slower on FF1
   p.wide = (!trans && wide_env && a->epilogue != LTXK_EPI_BIAS_GELU && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0) ? 1 : 0;
   const int tt_env = LTXK_AB_INT("LTXK_GEMM_TT", 0);
-  const int tt = (tt_env >= 1 && tt_env <= 5) ? tt_env : pick_tt(a->M, a->N);
+  const int nt_env = LTXK_AB_INT("LTXK_GEMM_NT", 0);                  // A/B build: 2 / 4 forces the 128- / 256-column tile
+  const bool nt2_legal = !split || a->n_split % 128 == 0;
+  TileChoice tc = pick_tile(a->M, a->N, nt_env == 2 && nt2_legal ? 2 : (nt_env == 4 || !nt2_legal ? 4 : 0));
+  if (tt_env >= 1 && tt_env <= 5) tc.tt = tt_env;
+  const int tt = tc.tt;
   const int bm = 32 * tt;
   p.RT = (a->M + bm - 1) / bm;
-  p.CT = (a->N + GEMM_BN - 1) / GEMM_BN;
+  p.CT = (a->N + 64 * tc.nt - 1) / (64 * tc.nt);
+  p.part = nullptr; p.ksteps = a->K / GEMM_BK;
   hipStream_t st = (hipStream_t)stream;
   const int big_env = LTXK_AB_INT("LTXK_GEMM_BIG", 1);
   const bool big_legal = a->N % BIG_BN == 0 && a->K <= (1 << 20) &&
                          (a->epilogue == LTXK_EPI_BIAS || ((a->epilogue == LTXK_EPI_BIAS_GELU || a->epilogue == LTXK_EPI_BIAS_SILU) && !a->sumsq));
   // A/B build: LTXK_GEMM_BIG=0 never, 2 / 3 the 320-row / 256-row tile whenever legal (tests compare the tiles bit for bit)
-  const int rb = !big_legal || tt_env != 0 || big_env == 0 ? 0 : (big_env == 2 ? 5 : (big_env == 3 ? 4 : big_tile_choice(a->M, a->N)));
+  const int rb = !big_legal || tt_env != 0 || nt_env != 0 || big_env == 0 ? 0 : (big_env == 2 ? 5 : (big_env == 3 ? 4 : big_tile_choice(a->M, a->N)));
   if (rb) {
     const int bm = 64 * rb;
     p.RT = (a->M + bm - 1) / bm;
@@ -896,18 +1165,46 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
       default: return launch_big<LTXK_EPI_BIAS_SILU, 0>(p, st, rb);
     }
   }
-  // (A persistent form for the multi-round launches - one workgroup per CU walking tiles b, b+256, ..., the LDS-DMA
-  // stream running on across tiles, the bias slice arriving by LDS-DMA, y = bf16(acc+bias) kept packed and its activation
-  // + stores deferred band by band into the next tile's first K-steps - was built, bit-identical, and measured on FF1
-  // in the same process: 316.7 us against 315.4 us plain (GELU), 312.6 against 312.9 (bias).  Hiding the 0.6 us dispatch
-  // gap, the 2.0 us fill and the 5-7 us epilogue of three tile transitions bought nothing: these launches are
-  // power-limited (1.67-1.74 GHz held), and what paid instead was moving fewer bytes - the XCD patch order of map_tile.
-  // Removed again; git history has it.)
-  switch (tt) {
-    case 5: return dispatch_epi<5>(p, a->epilogue, trans, st);
-    case 4: return dispatch_epi<4>(p, a->epilogue, trans, st);
-    case 3: return dispatch_epi<3>(p, a->epilogue, trans, st);
-    case 2: return dispatch_epi<2>(p, a->epilogue, trans, st);
-    default: return dispatch_epi<1>(p, a->epilogue, trans, st);
+  // Small M: the launch is a weight stream, and a 32..160-row tiling gives it far fewer workgroups than the chip has CUs (M=64,
+  // N=4096: 16 tiles of 256 columns - 16 CUs pulling 32 MB).  Split-K on the 128-column tile: every K slice is a workgroup of its
+  // own that parks its fp32 accumulators in the caller's workspace, and splitk_epilogue_kernel sums the slices in order and
+  // applies the epilogue (deterministic; fp32 sum of slice sums instead of one running sum: another summation order, one rounding).
+  {
+    const int ks_env = LTXK_AB_INT("LTXK_GEMM_KSPLIT", 0);           // A/B build: -1 never, n >= 2 forces n slices where legal
+    const int nk = a->K / GEMM_BK;
+    int S = 0;
+    if (ks_env >= 0 && rb == 0 && a->workspace != nullptr && nt2_legal && a->N % 4 == 0 && ((uintptr_t)a->workspace & 15) == 0 &&
+        (a->M <= LTXK_AB_INT("LTXK_GEMM_KSPLIT_MAXM", 640) || ks_env >= 2)) {
+      // the tallest row tile that covers M (every row tile re-streams its W slab), then as many K slices as fill the 256 CUs
+      // (one workgroup each: the deep ring takes most of a CU's LDS) - but never more fp32 slice traffic (S x M x N x 8 bytes,
+      // written and read back) than the weight panel itself (N x K x 2 bytes), and at least 8 K-steps per slice
+      const int tt2 = a->M >= 160 ? 5 : (a->M + 31) / 32;
+      const long tiles = ((long)(a->M + 32 * tt2 - 1) / (32 * tt2)) * ((a->N + 127) / 128);
+      const long have = ((long)p.RT * p.CT);
+      if (ks_env >= 2) S = ks_env;
+      else if (tiles <= 160 && have <= 200 && (long)a->N * a->K >= (1L << 21)) {     // a real weight stream (>= 4 MB) the tiling cannot spread
+        S = (int)((256 + tiles / 2) / tiles);
+        const int cap = a->K / (4 * a->M);
+        if (S > cap) S = cap;
+      }
+      if (S > nk / 8 && ks_env < 2) S = nk / 8;
+      if (S > nk) S = nk;
+      const long per = (long)a->M * a->N * 4;
+      if (S > 1 && (long)S * per > a->workspace_bytes) S = (int)(a->workspace_bytes / per);
+      if (S >= 2) {
+        p.RT = (a->M + 32 * tt2 - 1) / (32 * tt2);
+        p.CT = (a->N + 127) / 128;
+        p.ksteps = (nk + S - 1) / S;
+        S = (nk + p.ksteps - 1) / p.ksteps;                            // no empty slice
+        p.part = (float*)a->workspace;
+        const int rc = launch_partial(p, tt2, S, st);
+        if (rc != LTXK_OK) return rc;
+        const long threads = (long)a->M * (a->N / 4);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p, S, a->epilogue, trans ? 1 : 0);
+        LTXK_CHECK_LAUNCH("ltxk_gemm_bf16 (split-K epilogue)");
+        return LTXK_OK;
+      }
+    }
   }
+  return tc.nt == 2 ? dispatch_tt<2>(p, tt, a->epilogue, trans, st) : dispatch_tt<4>(p, tt, a->epilogue, trans, st);
 }

@@ -3,9 +3,10 @@
 //   C[m,n] = sum_k A[m,k] * W[n,k]          A rows and W rows are both k-contiguous bf16
 //
 // Geometry (gfx950, wave64): one workgroup = 8 waves = WM (rows) x WN (cols), WM*WN = 8;
-// tile BM x BN x 64 with BM = 16*TT*WM, BN = 64*WN; per wave TT x 4 MFMA tiles of
-// v_mfma_f32_16x16x32_bf16.  (TT=5, WN=4): 160x256, the Linear layers at M=2560;
-// (TT=4, WN=2): 256x128, the 128-channel convolutions.
+// tile BM x BN x 64 with BM = 16*TT*WM, BN = 16*NT*WN; per wave TT x NT MFMA tiles of
+// v_mfma_f32_16x16x32_bf16.  (TT=5, WN=4, NT=4): 160x256, the Linear layers at M=2560;
+// (TT=4, WN=2, NT=4): 256x128, the 128-channel convolutions; (TT=5, WN=4, NT=2): 160x128 with 80x32 per wave, the
+// Linear layers whose 256-column tiling leaves CUs idle (M=1280, N=4096: exactly 256 tiles; round 4).
 // Staging: global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into a 3-deep LDS ring; one
 // raw s_barrier per K-step, counted vmcnt so that two K-steps stay in flight across it.
 // LDS image: 128-byte rows ([row][64 bf16]) with the 16-byte chunk index XOR-swizzled by
@@ -34,11 +35,12 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T* opaque_gpt
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_THREADS = 512;
 
-template <int TT, int WN>
+template <int TT, int WN, int NT = 4>
 struct GemmGeom {
   static constexpr int WM = 8 / WN;
   static constexpr int BM = 16 * TT * WM;
-  static constexpr int BN = 64 * WN;
+  static constexpr int BN = 16 * NT * WN;
+  static_assert(BN % 64 == 0, "whole 1-KiB W pieces per wave");
   static constexpr int W_PIECES = BN / 8;          // 1 KiB pieces (8 rows x 128 B)
   static constexpr int W_PER_WAVE = W_PIECES / 8;
   static constexpr int W_STAGE_BYTES = BN * GEMM_BK * 2;
@@ -119,28 +121,28 @@ __device__ __forceinline__ void wait_stage_and_barrier(int keep) {
 // sprinkled one (or PPG) per group instead of being issued as a burst in front of the MFMAs — the
 // DMA issue cost (~60-180 cycles per 1-KiB piece) then hides under the matrix pipe.
 // issue(i): launch this wave's i-th LDS-DMA piece of the prefetched stage (no-op for i >= count).
-template <int TT, int WN, bool SWAP, class IssueFn>
+template <int TT, int WN, bool SWAP, int NT = 4, class IssueFn>
 __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int wn, int lane,
-                                                    f32x4 (&acc)[TT][4], IssueFn&& issue) {
-  using G = GemmGeom<TT, WN>;
+                                                    f32x4 (&acc)[TT][NT], IssueFn&& issue) {
+  using G = GemmGeom<TT, WN, NT>;
   constexpr int NG = 2 * TT;                                   // MFMA groups per K-step
   constexpr int MAXP = G::W_PER_WAVE + G::MAXA;                // LDS-DMA pieces per wave per stage
   constexpr int PPG = (MAXP + NG - 1) / NG;
-  const char* wb = st + (wn * 64) * 128 + (lane & 15) * 128;
+  const char* wb = st + (wn * 16 * NT) * 128 + (lane & 15) * 128;
   const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128 + (lane & 15) * 128;
   const int koff0 = (((lane >> 4)) ^ (lane & 7)) << 4;
   const int koff1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
-  bf16x8 wf[2][4], af[2][TT];
-  // flat read order: W0[0..3], A0[0..TT-1], W1[0..3], A1[0..TT-1]
+  bf16x8 wf[2][NT], af[2][TT];
+  // flat read order: W0[0..NT-1], A0[0..TT-1], W1[0..NT-1], A1[0..TT-1]
   auto rd = [&](int idx) {
     // idx is a compile-time constant after unrolling
-    const int ks = idx / (4 + TT), r = idx % (4 + TT);
+    const int ks = idx / (NT + TT), r = idx % (NT + TT);
     const int ko = ks ? koff1 : koff0;
-    if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
-    else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
+    if (r < NT) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
+    else af[ks][r - NT] = *(const bf16x8*)(ab + (r - NT) * 2048 + ko);
   };
-  constexpr int TOTAL = 2 * (4 + TT);
-  auto need = [](int g) { return (g / TT) * (4 + TT) + 4 + (g % TT) + 1; };
+  constexpr int TOTAL = 2 * (NT + TT);
+  auto need = [](int g) { return (g / TT) * (NT + TT) + NT + (g % TT) + 1; };
   int issued = 0;
 #pragma unroll
   for (int i = 0; i < TOTAL; ++i)
@@ -156,7 +158,7 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
     for (int q = 0; q < PPG; ++q) issue(g * PPG + q);
     const int ks = g / TT, tt = g % TT;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
       acc[tt][nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][tt], wf[ks][nt], acc[tt][nt], 0, 0, 0)
                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], af[ks][tt], acc[tt][nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
@@ -180,9 +182,9 @@ __device__ __forceinline__ void mma_stage_pipelined(const char* st, int wm, int 
 // all deferred groups use the ks=1 W fragments).  DG=2 hides the LDS cold start; DG=TT additionally puts a
 // wave half a K-step out of phase with a DG=2 wave — used for waves 4-7, the SIMD partners of waves 0-3, so
 // that the two waves of a SIMD do not hit their LDS-read bursts, DMA issues and MFMA-dense stretches together.
-template <int TT, int WN, bool SWAP, int DG = 2>
+template <int TT, int WN, bool SWAP, int DG = 2, int NT = 4>
 struct MmaPipe {
-  using G = GemmGeom<TT, WN>;
+  using G = GemmGeom<TT, WN, NT>;
   static constexpr int PD = LTXK_PREFETCH_GROUPS;   // fragment reads run PD MFMA groups ahead of their use
   static constexpr int NG = 2 * TT;
   static constexpr int MAXP = G::W_PER_WAVE + G::MAXA;
@@ -191,15 +193,15 @@ struct MmaPipe {
 #else
   static constexpr int PPG = (MAXP + NG - 1) / NG;
 #endif
-  static constexpr int TOTAL = 2 * (4 + TT);
+  static constexpr int TOTAL = 2 * (NT + TT);
   static_assert(TT >= 2 && DG >= 2 && DG <= TT, "deferred groups must all lie in the ks=1 half");
   // fragment registers persist across K-steps: after step() wf[1][*] and af[1][TT-DG..TT-1] hold the operands
   // of the deferred groups; the next step() consumes them before overwriting them.
-  bf16x8 wf[2][4], af[2][TT];
+  bf16x8 wf[2][NT], af[2][TT];
 
   __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) wf[1][i][j] = (bf16)0.f;
 #pragma unroll
@@ -208,36 +210,36 @@ struct MmaPipe {
       for (int j = 0; j < 8; ++j) af[1][i][j] = (bf16)0.f;
   }
 
-  static __device__ __forceinline__ void group(const bf16x8& a, const bf16x8 (&w)[4], f32x4 (&acc)[4]) {
+  static __device__ __forceinline__ void group(const bf16x8& a, const bf16x8 (&w)[NT], f32x4 (&acc)[NT]) {
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
       acc[nt] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w[nt], acc[nt], 0, 0, 0)
                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nt], a, acc[nt], 0, 0, 0);
   }
 
   template <class IssueFn>
-  __device__ __forceinline__ void step(const char* st, int wm, int wn, int lane, f32x4 (&acc)[TT][4], IssueFn&& issue) {
-    const char* wb = st + (wn * 64) * 128 + (lane & 15) * 128;
+  __device__ __forceinline__ void step(const char* st, int wm, int wn, int lane, f32x4 (&acc)[TT][NT], IssueFn&& issue) {
+    const char* wb = st + (wn * 16 * NT) * 128 + (lane & 15) * 128;
     const char* ab = st + G::W_STAGE_BYTES + (wm * TT * 16) * 128 + (lane & 15) * 128;
     const int koff0 = (((lane >> 4)) ^ (lane & 7)) << 4;
     const int koff1 = (((4 + (lane >> 4))) ^ (lane & 7)) << 4;
     auto rd = [&](int idx) {
-      const int ks = idx / (4 + TT), r = idx % (4 + TT);
+      const int ks = idx / (NT + TT), r = idx % (NT + TT);
       const int ko = ks ? koff1 : koff0;
 #ifdef LTXK_PROBE_FEWER_LDS_READS      // energy probe only (WRONG results): the ks=1 fragments are copies of the ks=0 ones
-      if (ks == 1) { if (r < 4) wf[1][r] = wf[0][r]; else af[1][r - 4] = af[0][r - 4]; return; }
+      if (ks == 1) { if (r < NT) wf[1][r] = wf[0][r]; else af[1][r - NT] = af[0][r - NT]; return; }
 #endif
-      if (r < 4) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
-      else af[ks][r - 4] = *(const bf16x8*)(ab + (r - 4) * 2048 + ko);
+      if (r < NT) wf[ks][r] = *(const bf16x8*)(wb + r * 2048 + ko);
+      else af[ks][r - NT] = *(const bf16x8*)(ab + (r - NT) * 2048 + ko);
     };
     // reads needed by real group g of THIS stage (flat order W0, A0[*], W1, A1[*]); g >= NG: everything
-    auto need = [](int g) { return g < 0 ? 0 : (g >= NG ? TOTAL : (g / TT) * (4 + TT) + 4 + (g % TT) + 1); };
+    auto need = [](int g) { return g < 0 ? 0 : (g >= NG ? TOTAL : (g / TT) * (NT + TT) + NT + (g % TT) + 1); };
     int issued = 0;
     // virtual groups: the DG groups deferred from the previous K-step (operands already in registers)
 #pragma unroll
     for (int v = 0; v < DG; ++v) {
       int target = need(v - DG + PD);
-      if (target > 4 + TT) target = 4 + TT;          // the ks=1 registers still feed the deferred groups
+      if (target > NT + TT) target = NT + TT;        // the ks=1 registers still feed the deferred groups
 #pragma unroll
       for (int i = 0; i < TOTAL; ++i)
         if (i >= issued && i < target) rd(i);
@@ -265,7 +267,7 @@ struct MmaPipe {
       if (i >= issued) rd(i);
   }
 
-  __device__ __forceinline__ void finish(f32x4 (&acc)[TT][4]) {
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TT][NT]) {
 #pragma unroll
     for (int v = 0; v < DG; ++v) group(af[1][TT - DG + v], wf[1], acc[TT - DG + v]);
   }

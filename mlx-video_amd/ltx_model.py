@@ -387,7 +387,9 @@ class LTXModel:
             # V^T transposed.  k is normalised + rotated in place; q stays RAW in HBM - the attention kernel normalises
             # and rotates its Q fragments in registers (attention.py:129-136).
             ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
-            if fq and not (self.fuse & 8):
+            # (fuse bit 8: q|k on the 320x256 tile with v as its own launch - a gain at M=2560 only; at small M every launch is a
+            # weight stream with ~5 us of fixed cost, so q|k|v stays ONE launch there)
+            if fq and (not (self.fuse & 8) or M <= ops.SPLITK_MAX_M):
                 ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=s_qk)
             else:
                 ops.gemm(nx, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=qk, sumsq=s_qk)

@@ -70,6 +70,20 @@ def _req(t: torch.Tensor, dtype, name: str) -> None:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+_GEMM_WS = {}
+GEMM_WORKSPACE_BYTES = 64 << 20
+SPLITK_MAX_M = 640          # rows up to which a launch is offered the split-K scratch (the library decides; gemm.hip)
+
+
+def _gemm_workspace(dev: torch.device) -> torch.Tensor:
+    """Per-device fp32 scratch handed to ltxk_gemm_bf16 for its split-K form at small M (caller-owned and reused by every
+    call on the stream - launches on one stream are ordered; the library never allocates)."""
+    key = dev.index if dev.index is not None else 0
+    if key not in _GEMM_WS:
+        _GEMM_WS[key] = torch.empty(GEMM_WORKSPACE_BYTES // 4, dtype=torch.float32, device=dev)
+    return _GEMM_WS[key]
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epilogue: int = EPI_BIAS,
          out: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          gate: Optional[torch.Tensor] = None, gate_row: Optional[torch.Tensor] = None,
@@ -106,6 +120,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, epil
     args.alpha = alpha
     args.out2, args.n_split, args.ldo2 = _p(out2), n_split, (out2.stride(-2) if out2 is not None else 0)
     args.sumsq, args.sumsq_ld = _p(sumsq), (sumsq.stride(0) if sumsq is not None else 0)
+    if M <= SPLITK_MAX_M:
+        ws = _gemm_workspace(a.device)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     with _timed("gemm_bf16", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
         check(_lib.load().ltxk_gemm_bf16(ctypes.byref(args), _stream()), "ltxk_gemm_bf16")
     return out

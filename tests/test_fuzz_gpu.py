@@ -24,9 +24,12 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def _gemm_cases(n=24):
+def _gemm_cases(n=29):
     rnd = random.Random(20261)
-    cases = [(1, 8, 64, "bias", 0), (161, 264, 64, "res", 4), (159, 248, 128, "gate_res", 0), (320, 512, 192, "gelu", 12)]
+    cases = [(1, 8, 64, "bias", 0), (161, 264, 64, "res", 4), (159, 248, 128, "gate_res", 0), (320, 512, 192, "gelu", 12),
+             # small M x long K: the split-K weight-streaming form (gemm.hip; config 1's geometry, M = B*32 tokens)
+             (64, 1024, 4096, "gate_res", 0), (64, 2048, 2048, "gelu", 0), (32, 512, 1024, "bias", 4), (320, 1024, 4096, "res", 0),
+             (200, 776, 1536, "silu", 12)]
     while len(cases) < n:
         M = rnd.choice([rnd.randint(1, 40), rnd.randint(100, 700)])
         N = 8 * rnd.randint(1, 140)

@@ -277,10 +277,12 @@ def test_latent_tokens_and_euler(dev):
 
 
 # ---------------------------------------------------------------------------------------------------- round 2: fused forms
-@pytest.mark.parametrize("M,T,D", [(2 * 1280, 1280, 4096), (2 * 77, 77, 512), (333, 333, 1024)])
+@pytest.mark.parametrize("M,T,D", [(2 * 1280, 1280, 4096), (2 * 77, 77, 512), (433, 433, 1024)])
 def test_gemm_split_output_and_sumsq(dev, M, T, D):
     """One launch over the packed q|k|v panel: columns [0,2D) row-major + their per-row sums of squares in 64-column
-    partials, columns [2D,3D) transposed per batch (V^T).  Each part must equal the separate launches bit for bit."""
+    partials, columns [2D,3D) transposed per batch (V^T).  Each part must equal the separate launches bit for bit.
+    (Row counts above the split-K range: whether a small-M launch sums K in slices depends on its column count, so launches
+    of different widths only agree bit for bit when they are single-pass; tests/test_gemm_epilogues_gpu.py covers split-K.)"""
     ops = _ops()
     g = torch.Generator().manual_seed(M + D)
     a = torch.randn(M, D, generator=g).to(BF).to(dev)
