@@ -176,7 +176,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
                    upsampler=None, prompt_embeds: Optional[torch.Tensor] = None,
                    negative_prompt_embeds: Optional[torch.Tensor] = None, text_encoder: Optional[Callable] = None,
                    noise_fn: Optional[Callable] = None, device=None, on_frames_ready: Optional[Callable] = None,
-                   return_latents: bool = False) -> np.ndarray:
+                   return_latents: bool = False, stage2_lora_in_place: Optional[bool] = None) -> np.ndarray:
     """See the module docstring.  Returns uint8 frames (F,H,W,3) (generate.py:4195-4197)."""
     t_start = time.perf_counter()
     if isinstance(pipeline, str):
@@ -223,6 +223,10 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         merged = apply_lora_to_weights(transformer_weights, [LoraSpec(Path(pth), float(st)) for pth, st in lora_list], verbose=verbose)
         return LTXModel(transformer_config or (transformer.config if transformer is not None else LTXModelConfig()), merged)
 
+    # stage-2 distilled LoRAs may be merged INTO the stage-1 model when nobody needs its un-merged weights again: by default
+    # only when the weights are loaded here (this call owns them); a caller that passes its own model opts in explicitly
+    if stage2_lora_in_place is None:
+        stage2_lora_in_place = transformer is None and transformer_weights is None
     if transformer is None and transformer_weights is None:
         if model_repo is None:
             raise FileNotFoundError("no transformer: pass transformer= or a local model_repo directory with LTX-2 safetensors")
@@ -289,7 +293,15 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         tr2 = stage2_transformer or transformer
         if distilled_loras:                                          # generate.py:3229-3237: base + distilled LoRAs only
             with timer.phase("stage2_transformer_load"):
-                tr2 = _with_loras(distilled_loras, "distilled_loras")
+                if stage2_lora_in_place and not loras:
+                    # the stage-1 model IS the base model and is not used again: merge into its own panels (same EPI_SCALE_RES
+                    # launches with the output aliasing the residual, same bits) instead of building a second 21-GB replica
+                    from .lora import LoraSpec, apply_lora_to_weights
+                    apply_lora_to_weights(transformer.weight_views(), [LoraSpec(Path(pth), float(st)) for pth, st in distilled_loras],
+                                          verbose=verbose, in_place=True)
+                    tr2 = transformer
+                else:
+                    tr2 = _with_loras(distilled_loras, "distilled_loras")
         pos2 = create_position_grid(1, latent_frames, s2h, s2w, fps=fps).to(dev)
         state2 = None
         if conds2:                                                  # generate.py:3290-3311

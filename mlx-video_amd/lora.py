@@ -103,7 +103,10 @@ def merge_lora_pair(w: torch.Tensor, A: torch.Tensor, B: torch.Tensor, strength:
 
 def _pack_group(As, Bs, device) -> Tuple[torch.Tensor, torch.Tensor]:
     """G pairs of one shape -> the two GEMM operand stacks on the device, built with ONE host->device copy and ONE
-    pad / transpose kernel each (not per pair): Bp (G,out,rp) and A^T (G,in,rp), rank zero-padded to rp = 64*ceil(r/64)."""
+    pad / transpose kernel each (not per pair): Bp (G,out,rp) and A^T (G,in,rp), rank zero-padded to rp = 64*ceil(r/64).
+    Deviation from the reference, stated: lora.py:114 multiplies B @ A in fp32 from the stored dtype; here the operands go to
+    the matrix cores as bf16 (exact for bf16 LoRA files - the published LTX-2 LoRAs; F16 / F32 files lose operand bits beyond
+    bf16's 8 before the fp32-accumulated product, parity unpinned for those) and the delta is rounded once, as in the reference."""
     r = As[0].shape[0]
     rp = (r + 63) // 64 * 64
     A_all = torch.stack([a.to(BF16) for a in As]).to(device, non_blocking=True)          # (G,r,in)
@@ -121,10 +124,12 @@ GROUP_MAX = 64      # pairs packed per host->device copy (bounds the staging mem
 
 
 def apply_lora_to_weights(weights: Dict[str, torch.Tensor], lora_specs: Iterable[LoraSpec], verbose: bool = False,
-                          lora_states: Dict[Path, Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                          lora_states: Dict[Path, Dict[str, torch.Tensor]] = None, in_place: bool = False) -> Dict[str, torch.Tensor]:
     """lora.py:94-127.  ``lora_states`` lets callers pass already-loaded LoRA tensors.  Pairs of one (A, B) shape are
     packed together (one copy + one pad/transpose kernel per group), then merged with one EPI_SCALE_RES GEMM launch per
-    weight; a weight touched by several LoRAs is merged in spec order, as the reference does."""
+    weight; a weight touched by several LoRAs is merged in spec order, as the reference does.  ``in_place``: the merged
+    values are written into the given tensors themselves (the GEMM's output aliases its residual operand: same launches,
+    same bits, no second copy of the model) - for callers that own ``weights`` and will not need the un-merged values again."""
     updated = dict(weights)
     for spec in lora_specs:
         sd = (lora_states or {}).get(spec.path)
@@ -146,8 +151,13 @@ def apply_lora_to_weights(weights: Dict[str, torch.Tensor], lora_specs: Iterable
                 Bp, At = _pack_group([a for _, a, _ in chunk], [b for _, _, b in chunk], dev)
                 for i, (key, _, _) in enumerate(chunk):
                     w = updated[key]
-                    updated[key] = ops.gemm(Bp[i], At[i], None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(),
-                                            alpha=float(spec.strength)).reshape(w.shape)
+                    if in_place:
+                        if w.dim() != 2 or not w.is_contiguous():
+                            raise ValueError(f"in-place LoRA merge needs a contiguous 2-D weight, got {key} {tuple(w.shape)}")
+                        ops.gemm(Bp[i], At[i], None, epilogue=ops.EPI_SCALE_RES, resid=w, out=w, alpha=float(spec.strength))
+                    else:
+                        updated[key] = ops.gemm(Bp[i], At[i], None, epilogue=ops.EPI_SCALE_RES, resid=w.contiguous(),
+                                                alpha=float(spec.strength)).reshape(w.shape)
                     applied += 1
         if verbose:
             print(f"[LoRA] {spec.path} applied={applied} skipped={skipped}")

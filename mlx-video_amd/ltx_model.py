@@ -191,6 +191,23 @@ class LTXModel:
             self.blocks.append(b)
         self.tables = torch.stack(tables, 0).contiguous()      # (L,6,D)
 
+    def weight_views(self) -> Dict[str, torch.Tensor]:
+        """Checkpoint key -> the (out,in) matrix as it lives inside THIS model: the packed q|k|v and text k|v panels are
+        returned as their row ranges.  Writing through these views changes the model (lora.apply_lora_to_weights(...,
+        in_place=True): the stage-2 transformer of the distilled pipeline without a second 21-GB replica, generate.py:3229-3283)."""
+        D = self.inner_dim
+        v = {"patchify_proj.weight": self.patchify_w, "adaln_single.emb.timestep_embedder.linear1.weight": self.t1_w,
+             "adaln_single.emb.timestep_embedder.linear2.weight": self.t2_w, "adaln_single.linear.weight": self.ada_w,
+             "caption_projection.linear1.weight": self.c1_w, "caption_projection.linear2.weight": self.c2_w, "proj_out.weight": self.out_w}
+        for i, b in enumerate(self.blocks):
+            pre = f"transformer_blocks.{i}"
+            for j, n in enumerate("qkv"):
+                v[f"{pre}.attn1.to_{n}.weight"] = b.wqkv[j * D:(j + 1) * D]
+            v[f"{pre}.attn1.to_out.weight"], v[f"{pre}.attn2.to_q.weight"] = b.wo, b.wq2
+            v[f"{pre}.attn2.to_k.weight"], v[f"{pre}.attn2.to_v.weight"] = b.wkv2[:D], b.wkv2[D:]
+            v[f"{pre}.attn2.to_out.weight"], v[f"{pre}.ff.proj_in.weight"], v[f"{pre}.ff.proj_out.weight"] = b.wo2, b.w1, b.w2
+        return v
+
     @staticmethod
     def expected_keys(cfg: LTXModelConfig) -> List[str]:
         keys = []

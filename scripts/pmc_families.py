@@ -54,24 +54,29 @@ for name, c in CASES.items():
         drv = os.path.join(root, "scripts", c["driver"][0])
         return [sys.executable, drv, str(iters), c["driver"][1]] if c.get("driver_iters_first") else [sys.executable, drv, c["driver"][1], str(iters)]
     vals = {}
+    # kernel trace first: the family's dominant kernel of this driver (a launch may come with a small tail launch of the same
+    # template); the counters below are taken from that kernel's largest grid only
+    d = os.path.join(outdir, f"{name}_trace")
+    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", *cmd(WARM + 6)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    tot = 0.0
+    for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+        for row in csv.DictReader(open(f, newline="")):
+            if c["match"] in row["Name"] and float(row["TotalDurationNs"]) > tot:
+                tot, vals["avg_ns"], vals["min_ns"], vals["kernel"] = float(row["TotalDurationNs"]), float(row["AverageNs"]), float(row["MinNs"]), row["Name"]
     for pname, counters in PASSES.items():
         d = os.path.join(outdir, f"{name}_{pname}")
         subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *cmd(WARM + 3)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        acc = {}
+        rows = []
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-            for row in csv.DictReader(open(f, newline="")):
-                if c["match"] in row["Kernel_Name"]:
-                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            rows += [r for r in csv.DictReader(open(f, newline="")) if r["Kernel_Name"] == vals.get("kernel")]
+        grid = max((int(r["Grid_Size"]) for r in rows), default=0)
+        acc = {}
+        for r in rows:
+            if int(r["Grid_Size"]) == grid:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for cn, v in acc.items():
             v = v[WARM:] if len(v) > WARM else v
             vals[cn] = sum(v) / len(v)
-    d = os.path.join(outdir, f"{name}_trace")
-    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", *cmd(WARM + 6)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
-        for row in csv.DictReader(open(f, newline="")):
-            if c["match"] in row["Name"] and float(row["TotalDurationNs"]) > vals.get("_tot", 0.0):        # the family's dominant kernel of this driver
-                vals["_tot"], vals["avg_ns"], vals["min_ns"], vals["kernel"] = float(row["TotalDurationNs"]), float(row["AverageNs"]), float(row["MinNs"]), row["Name"]
-    vals.pop("_tot", None)
     e = {"family": c["family"], "shape": c["shape"], "kernel": vals.get("kernel"), "counters": vals, "algorithmic_bytes": c["algorithmic_bytes"]}
     if "FETCH_SIZE" in vals:
         e["FETCH_SIZE_KiB"], e["WRITE_SIZE_KiB"] = vals["FETCH_SIZE"], vals.get("WRITE_SIZE")

@@ -66,19 +66,29 @@ runs = [
     ("config1 dev 128x128x9 1 step", dict(pipeline=PipelineType.DEV, height=128, width=128, num_frames=9, num_inference_steps=1)),
     ("config2 dev 512x512x33 40 steps CFG4", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=33, num_inference_steps=40)),
     ("config4 (one seed) dev 512x512x97 40 steps CFG4, temporal-tiled decode", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=97, num_inference_steps=40, tiling="temporal")),
-    ("config3 distilled 768x768x65 two-stage + 2x upsampler, distilled LoRA (rank 64) merged into stage 2", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
-                                                 distilled_loras=[(lora64, 0.8)])),
     ("config5 ic_lora 768x768x65 video-cond, merged LoRA (rank 64)", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
                                                  loras=[(lora64, 1.0)],
                                                  video_conditionings=[((torch.rand((1, 3, 65, 768, 768), generator=g, device=dev) * 2 - 1).to(BF), 0, 1.0)])),
+    ("config3 distilled 768x768x65 two-stage + 2x upsampler, distilled LoRA (rank 64) merged IN PLACE into the stage-1 model for stage 2 (run last: it consumes the model)", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 distilled_loras=[(lora64, 0.8)], stage2_lora_in_place=True)),
 ]
 for name, kw in runs:
     pj = f"/tmp/prof_{abs(hash(name))}.json"
+    torch.cuda.reset_peak_memory_stats()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     fr = generate_video(prompt="x", transformer=tr, transformer_weights=Wt, transformer_config=cfg, vae_decoder=dec, vae_encoder=enc, upsampler=ups, prompt_embeds=emb,
                         negative_prompt_embeds=neg, cfg_scale=4.0, compile_step=True, cfg_batch=True, device=dev, seed=7,
                         profile_json_path=pj, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ph = json.load(open(pj))["phases_s"]
-    print(json.dumps({"config": name, "frames": list(fr.shape), "wall_s": round(dt, 3), "phases_s": {k: round(v, 4) for k, v in ph.items()},
+    # achieved PFLOP/s of each denoise phase: SURVEY 8d's algorithmic FLOPs (bench.dit_forward_flops) x forwards / phase time
+    from bench import dit_forward_flops
+    H32, W32, Fl = kw["height"] // 32, kw["width"] // 32, 1 + (kw["num_frames"] - 1) // 8
+    pf = {}
+    if "dev_denoise" in ph:
+        pf["dev_denoise"] = kw["num_inference_steps"] * dit_forward_flops(Fl * H32 * W32, B=2, L=layers) / ph["dev_denoise"] / 1e15
+    if "stage1_denoise" in ph:
+        pf["stage1_denoise"] = kw["stage1_steps"] * dit_forward_flops(Fl * (H32 // 2) * (W32 // 2), B=1, L=layers) / ph["stage1_denoise"] / 1e15
+        pf["stage2_denoise"] = kw["stage2_steps"] * dit_forward_flops(Fl * H32 * W32, B=1, L=layers) / ph["stage2_denoise"] / 1e15
+    print(json.dumps({"config": name, "frames": list(fr.shape), "wall_s": round(dt, 3), "phases_s": {k: round(v, 4) for k, v in ph.items()}, "achieved_PFLOPs": {k: round(v, 3) for k, v in pf.items()},
                       "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)

@@ -163,6 +163,13 @@ def test_two_stage_pipelines_match_oracle_at_768x768x65(dev, tmp_path, pipe):
                           (12, 12), (24, 24), sig1, sig2, conds1, conds2, p, compiled=False)
     parity.check(f"pipeline.{pipe}_768x768x65.final_latents_vs_oracle", rel_l2(lat.float(), r2), 2.5e-2)
     if pipe != "ic_lora":
+        # stage-2 LoRA merged INTO the stage-1 model (no second replica; generate_video's default when it loads the weights
+        # itself): the same EPI_SCALE_RES launches with the output aliasing the residual -> bit-identical latents
+        from mlx_video_amd.ltx_model import LTXModel
+        own = {k: v.clone() for k, v in Wdev.items()}
+        lat_ip = generate_video(pipeline=PipelineType.DISTILLED, images=[(img, 0, 1.0)], distilled_loras=[(str(lora_path), 0.8)],
+                                **dict(kw, noise_fn=_Noise(9, dev), transformer=LTXModel(mc, own), transformer_weights=own, stage2_lora_in_place=True))
+        assert torch.equal(lat_ip, lat)
         # the stage-2 LoRA must matter: the same run without it lands measurably elsewhere
         noise2 = _Noise(9, dev)
         kw2 = dict(kw, noise_fn=noise2)
@@ -300,3 +307,12 @@ def test_lora_merge_4096(dev, rank):
     parity.check(f"lora.merge_4096_rank{rank}.mismatch_fraction", frac, 2e-3)
     parity.check(f"lora.merge_4096_rank{rank}.rel_l2", rel_l2(out.float(), ref.float()), 2e-4)
     assert float(diff.max()) <= 2 * float(ref.float().abs().max()) * 2 ** -8
+    # merged IN PLACE (the stage-2 transformer without a second replica): a row range of a packed (3*4096, 4096) panel written
+    # through a view, output aliasing the residual - the same bits as the fresh build, the rest of the panel untouched
+    from mlx_video_amd.lora import LoraSpec, apply_lora_to_weights
+    panel = torch.cat([torch.full((4096, 4096), 3.0, dtype=BF), Wt, torch.full((4096, 4096), 5.0, dtype=BF)], 0).to(dev)
+    sd = {"diffusion_model.blk.attn1.to_k.lora_A.weight": A.to(dev), "diffusion_model.blk.attn1.to_k.lora_B.weight": B.to(dev)}
+    spec = LoraSpec("in-memory", 0.75)
+    apply_lora_to_weights({"blk.attn1.to_k.weight": panel[4096:8192]}, [spec], lora_states={spec.path: sd}, in_place=True)
+    torch.cuda.synchronize()
+    assert torch.equal(panel[4096:8192], out) and bool((panel[:4096] == 3.0).all()) and bool((panel[8192:] == 5.0).all())
