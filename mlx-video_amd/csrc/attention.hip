@@ -41,6 +41,7 @@ struct FaParams {
   int QT;    // query tiles per (batch, head)
   int xcd;   // 1: all query tiles of a (batch, head) run on one XCD (its K / V^T stay in that XCD's L2)
   int n_full, rem;   // tiles run as full workgroups / tiles split over two tail workgroups each
+  int n_a, qta, qtb; // mixed grid (flash_attn16_mix_kernel): workgroups [0, n_a) are 192-row tiles (qta per (batch, head)), the rest 128-row tiles (qtb each)
   // fused query preparation (attention.py:129-136): q holds the RAW to_q output; its per-row sums of squares come as
   // q_ss_n fp32 partials per row (the GEMM's sumsq output), the kernel applies RMSNorm (all heads jointly) * weight and
   // the SPLIT rotation to its Q fragments in registers - the normalised / rotated q never makes a trip through HBM
@@ -442,11 +443,12 @@ __device__ __forceinline__ int fa16_kswz(int row) { return 4 * ((row >> 3) & 3) 
 // RMSNorm * weight (+ SPLIT RoPE) of the wave's Q fragments in the 16x16x32 operand map: fragment (qb, ks) of lane (c,g)
 // holds channels 32ks + 8g + j; the rotation partner 64 channels up is fragment ks + 2 of the same lane.  Same op order
 // and rounding points as fa_prep_q / qknorm_rope_kernel.
-__device__ __forceinline__ void fa16_prep_q(const FaParams& p, bf16x8 (&qf)[2][4], int b, int h, int q0, int c, int g) {
+template <int QB>
+__device__ __forceinline__ void fa16_prep_q(const FaParams& p, bf16x8 (&qf)[QB][4], int b, int h, int q0, int c, int g) {
   const int half = p.q_ss_n >> 1;
   const bf16* wp = p.q_w + h * FA_DH + g * 8;
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     int qrow = q0 + 16 * qb + c;
     qrow = qrow < p.Tq ? qrow : p.Tq - 1;
     const float* sp = p.q_ss + (size_t)(b * p.Tq + qrow) * p.q_ss_ld + (g & 1) * half;
@@ -486,16 +488,20 @@ __device__ __forceinline__ void fa16_prep_q(const FaParams& p, bf16x8 (&qf)[2][4
   }
 }
 
-template <int KS>
+template <int KS, int QB = 2>
 __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh, int q0, int kh, int wave, int lane) {
   constexpr int NW = 4;
   constexpr int NKC = 2 / KS;                    // 32-key chunks of a tile this wave works on
   const int c = lane & 15, g = lane >> 4;
   const int b = bh / p.H, h = bh - b * p.H;
 
-  // ---- Q: the wave's 32 x 256-byte block by LDS-DMA into its private corner of ring slot 1 (rows swizzled by row & 15) ----
-  bf16x8 qf[2][4];
-  {
+  // ---- Q.  QB = 2: the wave's 32 x 256-byte block by LDS-DMA into its private corner of ring slot 1 (rows swizzled by row & 15;
+  // the slot is free until tile 1 is fetched, after the loop's first barrier).  QB = 3: 48 rows per wave would need 48 KiB of
+  // staging - 80 KiB per workgroup, and two workgroups no longer share a CU - so the fragments come straight from global memory
+  // (12 loads of 16 B per lane, once per kernel; hipcc's own counted waits stay correct with the LDS-DMA pieces issued behind them:
+  // vmcnt retires in order and younger operations only make its waits conservative) ----
+  bf16x8 qf[QB][4];
+  if constexpr (QB == 2) {
     char* qreg = smem + FA_STAGE + wave * 8192;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -503,6 +509,15 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
       int qrow = q0 + row;
       qrow = qrow < p.Tq ? qrow : p.Tq - 1;
       glds16(p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + (((lane & 15) ^ (row & 15)) << 3), qreg + j * 1024);
+    }
+  } else {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      int qrow = q0 + 16 * qb + c;
+      qrow = qrow < p.Tq ? qrow : p.Tq - 1;
+      const bf16* qp = p.q + ((size_t)b * p.Tq + qrow) * p.ldq + h * FA_DH + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const bf16x8*)(qp + ks * 32);
     }
   }
   // ---- loader addressing: K piece = 4 key rows x 256 B (chunk position = chunk ^ kswz(row)); V^T piece = 8 d-rows x 128 B ----
@@ -535,30 +550,32 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
     glds16_s((uint64_t)(uintptr_t)vbase + (uint64_t)t * vstep, voff[i], smem + st * FA_STAGE + FA_K_BYTES + (wave + i * NW) * 1024);
   };
 
-  f32x4 o[8][2];
+  f32x4 o[8][QB];
 #pragma unroll
   for (int db = 0; db < 8; ++db)
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[db][qb][j] = 0.f;
-  float mc_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};     // per query block qb (query row 16qb + c)
+  float mc_run[QB], l_run[QB];                                     // per query block qb (query row 16qb + c)
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { mc_run[qb] = -1e30f; l_run[qb] = 0.f; }
 
   const int nt = (p.Tk + FA_BK - 1) / FA_BK;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { issue_k(i, 0, 0); issue_v(i, 0, 0); }
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the 8 Q pieces have landed
-  {
+  if constexpr (QB == 2) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the 8 Q pieces have landed
     const char* qreg = smem + FA_STAGE + wave * 8192;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int row = 16 * qb + c;
         qf[qb][ks] = *(const bf16x8*)(qreg + row * 256 + (((4 * ks + g) ^ (row & 15)) << 4));
       }
   }
-  if (p.q_ss) fa16_prep_q(p, qf, b, h, q0, c, g);
+  if (p.q_ss) fa16_prep_q<QB>(p, qf, b, h, q0, c, g);
 
   for (int t = 0; t < nt; ++t) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -570,35 +587,44 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
 
     // ---- S^T = K . Q^T: one group of 8 MFMAs per 16-key block (4 K fragments x 2 query blocks); the next block's
     // fragments are requested before this block's MFMAs issue; one K and one V^T piece of the next tile per group ----
-    f32x4 s[2 * NKC][2];
+    f32x4 s[2 * NKC][QB];
 #pragma unroll
     for (int i = 0; i < 2 * NKC; ++i)
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[i][qb][j] = 0.f;
     {
       constexpr int NG = 2 * NKC;
-      bf16x8 kfr[2][4];
-      auto load_k = [&](bf16x8* dst, int gi) __attribute__((always_inline)) {
+      constexpr int KBUF = QB >= 3 ? 1 : 2;      // QB = 3: 240+ live registers - ONE fragment set, each register refilled as soon as its MFMAs have issued
+      bf16x8 kfr[KBUF][4];
+      auto load_k1 = [&](bf16x8& dst, int gi, int ks) __attribute__((always_inline)) {
         const int kb = (KS == 1 ? gi : 2 * kh + gi);
         const int row = fa16_keymap(kb, c);
-        const int sw = c;                                     // = fa16_kswz(row)
+        dst = *(const bf16x8*)(sk + row * 256 + (((4 * ks + g) ^ c) << 4));      // swizzle = fa16_kswz(row) = c
+      };
+      auto load_k = [&](bf16x8* dst, int gi) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(sk + row * 256 + (((4 * ks + g) ^ sw) << 4));
+        for (int ks = 0; ks < 4; ++ks) load_k1(dst[ks], gi, ks);
       };
       load_k(kfr[0], 0);
 #pragma unroll
       for (int gi = 0; gi < NG; ++gi) {
-        if (gi + 1 < NG) load_k(kfr[(gi + 1) & 1], gi + 1);
+        if (KBUF == 2 && gi + 1 < NG) load_k(kfr[(gi + 1) & 1], gi + 1);
         if (KS == 1) { issue_k(gi, tn, stn); issue_v(gi, tn, stn); }
         else { issue_k(2 * gi, tn, stn); issue_k(2 * gi + 1, tn, stn); issue_v(2 * gi, tn, stn); issue_v(2 * gi + 1, tn, stn); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb)
-            s[gi][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[gi & 1][ks], qf[qb][ks], s[gi][qb], 0, 0, 0);
+          for (int qb = 0; qb < QB; ++qb)
+            s[gi][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[gi % KBUF][ks], qf[qb][ks], s[gi][qb], 0, 0, 0);
+          if (KBUF == 1 && gi + 1 < NG) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_k1(kfr[0][ks], gi + 1, ks);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       }
     }
     // V^T fragments of the first P.V group (d block 0): requested now, they land under the softmax
@@ -613,7 +639,7 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
         dst[i] = *(const bf16x8*)(vrow + (((4 * kc + g) ^ sw) << 4));
       }
     };
-    load_v(vfr[0], 0);
+    if (QB < 3) load_v(vfr[0], 0);                 // (QB = 3: no register to spare under the softmax - requested after it)
     __builtin_amdgcn_sched_barrier(0);
     // ---- mask the ragged key tail (last tile only) ----
     if (t == nt - 1 && (p.Tk & (FA_BK - 1)) != 0) {
@@ -623,25 +649,30 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int key = t * FA_BK + 32 * (kb >> 1) + 8 * g + 4 * (kb & 1) + j;      // fa16_keymap(kb, 4g + j)
-          if (key >= p.Tk) { s[i][0][j] = -1e30f; s[i][1][j] = -1e30f; }
+          if (key >= p.Tk) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) s[i][qb][j] = -1e30f;
+          }
         }
       }
     }
     // ---- online softmax per query block (key axis = registers x lane groups g) ----
-    float mxc[2];
+    float mxc[QB];
+    bool grow = false;
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       float mx = s[0][qb][0];
 #pragma unroll
       for (int i = 0; i < 2 * NKC; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[i][qb][j]);
       mxc[qb] = mx * p.c;                                   // this lane's keys only: enough for the deferral test (see fa_body)
+      grow |= mxc[qb] - mc_run[qb] > FA_DEFER;
     }
-    if (__any(mxc[0] - mc_run[0] > FA_DEFER || mxc[1] - mc_run[1] > FA_DEFER)) {
+    if (__any(grow)) {
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < QB; ++qb) {
         const float m_new = fmaxf(mc_run[qb], __builtin_ceilf(lane_xor32_max(lane_xor16_max(mxc[qb]))));
         const float alpha = __builtin_amdgcn_exp2f(mc_run[qb] - m_new);
         mc_run[qb] = m_new;
@@ -652,9 +683,9 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
           for (int j = 0; j < 4; ++j) o[db][qb][j] *= alpha;
       }
     }
-    bf16x8 pb[NKC][2];
+    bf16x8 pb[NKC][QB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       const float mc = mc_run[qb];
       float psum = 0.f;
 #pragma unroll
@@ -668,6 +699,7 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
       l_run[qb] += psum;
     }
     // ---- O^T += V^T . P^T: one group per 16-channel block (2 chunks x 2 query blocks), next block's fragments first ----
+    if (QB >= 3) load_v(vfr[0], 0);
 #pragma unroll
     for (int db = 0; db < 8; ++db) {
       if (db + 1 < 8) load_v(vfr[(db + 1) & 1], db + 1);
@@ -675,16 +707,17 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
 #pragma unroll
       for (int i = 0; i < NKC; ++i)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < QB; ++qb)
           o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[db & 1][i], pb[i][qb], o[db][qb], 0, 0, 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  float l_tot[2];
+  float l_tot[QB];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) l_tot[qb] = lane_xor32_sum(lane_xor16_sum(l_run[qb]));
-  if (KS == 2) {
+  for (int qb = 0; qb < QB; ++qb) l_tot[qb] = lane_xor32_sum(lane_xor16_sum(l_run[qb]));
+  if constexpr (KS == 2) {
+    static_assert(QB == 2, "the key-split tail workgroups are built for two query blocks per wave");
     // ---- merge the key halves of each wave pair through LDS (the K / V^T ring is dead now) ----
     __syncthreads();
     float* xo = (float*)(smem + (wave >> 1) * (17 * 1024));
@@ -712,11 +745,11 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
         for (int j = 0; j < 4; ++j) o[db][qb][j] = o[db][qb][j] * a0 + xo[((db * 2 + qb) * 4 + j) * 64 + lane] * a1;
     }
   }
-  // ---- epilogue: O[q][d] = O^T[d][q] / l through a wave-private 8 KiB LDS image, whole 256-byte rows out ----
+  // ---- epilogue: O[q][d] = O^T[d][q] / l through a wave-private 4*QB KiB LDS image, whole 256-byte rows out ----
   if (KS == 1) __syncthreads();
-  char* stg = smem + (KS == 1 ? wave * 8192 : 2 * 17 * 1024 + (wave >> 1) * 8192);
+  char* stg = smem + (KS == 1 ? wave * (4096 * QB) : 2 * 17 * 1024 + (wave >> 1) * 8192);
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const float inv = 1.0f / l_tot[qb];
     const int row = 16 * qb + c;
 #pragma unroll
@@ -731,7 +764,7 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
   {
     bf16* ob = p.out + ((size_t)b * p.Tq) * p.ldo + h * FA_DH + (lane & 15) * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4 * QB; ++i) {
       const int row = i * 4 + (lane >> 4);
       const bf16x8 v = *(const bf16x8*)(stg + row * 256 + (((lane & 15) ^ (row & 15)) << 4));
       if (q0 + row < p.Tq) *(bf16x8*)(ob + (size_t)(q0 + row) * p.ldo) = v;
@@ -755,6 +788,63 @@ __global__ __launch_bounds__(256, 2) void flash_attn16_kernel(FaParams p) {
     fa_map(p, tile, bh, qt);
     fa_body16<2>(p, smem, bh, qt * 128 + half * 64 + (wave >> 1) * FA_QW, wave & 1, wave, lane);
   }
+}
+
+// Query blocks per wave (round 4).  With 16-row MFMA blocks a wave can own two blocks (32 rows, 128-row workgroups: the kernel
+// above) or three (48 rows, 192-row workgroups): every K / V^T fragment read then feeds three MFMAs instead of two, and a workgroup
+// stages its K / V^T tiles for 1.5x the rows - measured 12 % cheaper per query row at equal fill (one full round of 512 workgroups:
+// Tq=1536 in 62.4 us against Tq=1024 in 47.6 us at Tk=1280, B=2, H=32; 5184^2: 700 against 772 us = 1.26 PF/s;
+// profiles/r04_attn_qb_ab.log), at 256 registers per lane with one K fragment set instead of two.  Four blocks need more than the
+// 256 registers two waves per SIMD leave each (o alone is 128).  What a grid of 192-row tiles loses is balance: N=1280 is 6.67 of
+// them.  So ONE launch mixes the two sizes: per (batch, head) `qta` tiles of 192 rows followed by `qtb` tiles of 128 rows, chosen by
+// fa_pick_mix below; all 192-row workgroups come first in the grid, so that a CU that is handed two workgroups at a time gets its
+// share of each kind (N=1280, B*H=64: 4 x (192 + 128) rows = 256 + 256 workgroups = one of each per CU = 80 rows per SIMD, the
+// chip's exact share; placement is the dispatcher's and affects speed only).  No key split anywhere: a row's result does not
+// depend on the batch it is launched in (the bits of LTXK_ATTN_NO_TAIL_SPLIT).
+constexpr int FA_LDS_MIX = FA_LDS;                   // two workgroups per CU (the 192-row form's output staging, 4 x 12 KiB, reuses the dead ring)
+__global__ __launch_bounds__(256, 2) void flash_attn16_mix_kernel(FaParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bh, qt;
+  if ((int)blockIdx.x < p.n_a) {
+    p.QT = p.qta;
+    fa_map(p, blockIdx.x, bh, qt);
+    fa_body16<1, 3>(p, smem, bh, qt * 192 + wave * 48, 0, wave, lane);
+  } else {
+    p.QT = p.qtb;
+    fa_map(p, blockIdx.x - p.n_a, bh, qt);
+    fa_body16<1, 2>(p, smem, bh, p.qta * 192 + qt * 128 + wave * 32, 0, wave, lane);
+  }
+}
+
+// (qta, qtb) for Tq rows per (batch, head): qtb in 0..6 tiles of 128 rows, the rest in 192-row tiles, minimising the busiest CU's
+// load in a model of the launch - workgroups dealt in grid order to the least-loaded of `cus` CUs, a CU's time = the summed cost
+// of its workgroups (two co-resident workgroups share its matrix pipe), cost = rows (x 0.875 for the 192-row form, measured) +
+// a fixed part (prologue, Q staging, output tail ~ 2 key tiles' worth).  Returns the model's makespan.
+static long fa_pick_mix(int Tq, int Tk, int BH, int cus, int& qta, int& qtb) {
+  long best = -1;
+  if (cus > 1024) cus = 1024;
+  const long fixed = 8L * 128 * 128 / (Tk < 128 ? 128 : Tk);    // in rows x 8: the fixed part of a workgroup ~ 128 keys' worth of a 128-row tile
+  const long ca = 192 * 7 + fixed, cb = 128 * 8 + fixed;        // 0.875 per row of a 192-row tile
+  for (int nb = 0; nb <= 6; ++nb) {
+    const int rest = Tq - 128 * nb;
+    if (rest <= -128) break;                                     // more 128-row tiles than rows
+    const int na = rest > 0 ? (rest + 191) / 192 : 0;
+    long load[1024];
+    const long wa = (long)na * BH, wb = (long)nb * BH;
+    for (int c = 0; c < cus; ++c) load[c] = (wa / cus + (c < wa % cus ? 1 : 0)) * ca;      // 192-row workgroups, round-robin
+    for (long i = 0; i < wb; ++i) {                              // 128-row workgroups onto the least-loaded CU
+      int m = 0;
+      for (int c = 1; c < cus; ++c)
+        if (load[c] < load[m]) m = c;
+      load[m] += cb;
+    }
+    long span = 0;
+    for (int c = 0; c < cus; ++c) span = load[c] > span ? load[c] : span;
+    if (best < 0 || span < best) { best = span; qta = na; qtb = nb; }
+  }
+  return best;
 }
 
 }  // namespace ltxk
@@ -796,6 +886,12 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
     if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
     attr_dev = dev;
   }
+  static thread_local int slots = 0;
+  if (slots == 0) {
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = 2 * cus;
+  }
   // Forms measured and removed again (numbers at B=2,H=32, Tq=Tk=1280 / 5184, round 1): an 8-wave ping-pong kernel with a
   // 4-deep 128 KiB ring 565 / 930 TF/s, a 5-wave 160-row form 554 / 580, a 48-KiB 3-workgroup form ~430, against 630 / 945
   // for this one.  Round 2 (same box, interleaved rounds; this kernel 52.6 us at Tq=1024,Tk=1280 and 864 us at 5184^2):
@@ -819,12 +915,6 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // launch without a short round (e.g. B=1 vs B=2), so batching changes low-order bits; LTXK_ATTN_NO_TAIL_SPLIT in
   // args->flags restores batch-invariant results (an explicit ABI field because it changes output bits).
   const int split = (a->flags & LTXK_ATTN_NO_TAIL_SPLIT) ? 0 : 1;
-  static thread_local int slots = 0;
-  if (slots == 0) {
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = 2 * cus;
-  }
   const int tiles = p.QT * B * H;
   p.n_full = tiles; p.rem = 0;
   if (split && tiles % slots != 0) {
@@ -835,6 +925,39 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
     const int r = tiles % slots;
     p.rem = 2 * r <= slots ? r : (LTXK_AB_INT("LTXK_FA_FILL", 1) ? slots - r : 0);
     p.n_full = tiles - p.rem;
+  }
+  p.n_a = 0; p.qta = 0; p.qtb = 0;
+  // More than one 128-row tile per (batch, head): the mixed 192 / 128-row grid (flash_attn16_mix_kernel).  A/B build: LTXK_FA_QB=2
+  // keeps the 128-row kernel with its tail split everywhere, 3 forces 192-row tiles only.
+  // Which grid (same box, interleaved, B*H = 32 / 64 / 128; profiles/r04_attn_qb_ab.log): from 1.25 rounds of 128-row tiles up the
+  // mixed grid wins by 9-15 % (1280^2 B=2: 56.8 -> 49.7 us, 1296^2: 68.4 -> 57.8, 5184^2: 772 -> 702, B=4 1280^2: 108 -> 98); below
+  // that the chip has fewer workgroups than slots, a CU runs one workgroup - one wave per SIMD, ~0.8 of the shared rate - and the
+  // 128-row kernel's key-split tail, which doubles the workgroups, is the faster form (B=1 1280^2: 32.7 against 35.5 us).
+  const int qb_env = LTXK_AB_INT("LTXK_FA_QB", 0);
+  const long tiles128 = (long)((Tq + 127) / 128) * B * H;
+  if (Tq > 128 && qb_env != 2 && (qb_env == 3 || 4 * tiles128 >= 5L * slots) && LTXK_AB_INT("LTXK_FA_MFMA", FA_DEFAULT_MFMA) == 16) {
+    static thread_local int attr_devm = -1;
+    if (dev != attr_devm) {
+      hipError_t e = hipFuncSetAttribute((const void*)flash_attn16_mix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS_MIX);
+      if (e != hipSuccess) { ltxk_set_error("ltxk_flash_attn_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LTXK_ELAUNCH; }
+      attr_devm = dev;
+    }
+    static thread_local int c_tq = 0, c_tk = 0, c_bh = 0, c_qta = 0, c_qtb = 0;      // last two decisions (a forward repeats two shapes)
+    static thread_local int c2_tq = 0, c2_tk = 0, c2_bh = 0, c2_qta = 0, c2_qtb = 0;
+    int qta, qtb;
+    if (qb_env == 3) { qta = (Tq + 191) / 192; qtb = 0; }
+    else if (Tq == c_tq && Tk == c_tk && B * H == c_bh) { qta = c_qta; qtb = c_qtb; }
+    else if (Tq == c2_tq && Tk == c2_tk && B * H == c2_bh) { qta = c2_qta; qtb = c2_qtb; }
+    else {
+      fa_pick_mix(Tq, Tk, B * H, slots / 2, qta, qtb);
+      c2_tq = c_tq; c2_tk = c_tk; c2_bh = c_bh; c2_qta = c_qta; c2_qtb = c_qtb;
+      c_tq = Tq; c_tk = Tk; c_bh = B * H; c_qta = qta; c_qtb = qtb;
+    }
+    p.qta = qta; p.qtb = qtb; p.n_a = qta * B * H;
+    p.n_full = (qta + qtb) * B * H; p.rem = 0;
+    hipLaunchKernelGGL(flash_attn16_mix_kernel, dim3((unsigned)p.n_full), dim3(256), FA_LDS_MIX, (hipStream_t)stream, p);
+    LTXK_CHECK_LAUNCH("ltxk_flash_attn_bf16");
+    return LTXK_OK;
   }
   const dim3 grid((unsigned)(p.n_full + 2 * p.rem));
   if (LTXK_AB_INT("LTXK_FA_MFMA", FA_DEFAULT_MFMA) == 16) {

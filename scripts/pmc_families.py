@@ -68,7 +68,9 @@ for name, c in CASES.items():
         subprocess.run(["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", *cmd(WARM + 3)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         rows = []
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-            rows += [r for r in csv.DictReader(open(f, newline="")) if r["Kernel_Name"] == vals.get("kernel")]
+            allr = [r for r in csv.DictReader(open(f, newline="")) if c["match"] in r["Kernel_Name"]]
+            exact = [r for r in allr if r["Kernel_Name"] == vals.get("kernel")]
+            rows += exact if exact else allr          # (the two files name a kernel the same way; if not, the largest grid decides)
         grid = max((int(r["Grid_Size"]) for r in rows), default=0)
         acc = {}
         for r in rows:
