@@ -584,6 +584,12 @@ def main() -> None:
                     "launches": vres.get("vae_conv3d_launches"),
                     "avg_ms": (vres["vae_kernel_breakdown_ms"]["conv3d_k3"] / vres["vae_conv3d_launches"]
                                if vres.get("vae_conv3d_launches") and "vae_kernel_breakdown_ms" in vres else None)}
+            if "vae_pixelnorm_GBs" in vres:
+                result["roofline_by_family"]["pixelnorm_act"] = {
+                    "kernel": "ltxk::pixelnorm_act_kernel (algorithmic bytes: read x, write y)", "bound": "hbm", "achieved": vres["vae_pixelnorm_GBs"],
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": vres["vae_pixelnorm_GBs"] / PEAK_HBM_GBS,
+                    "traffic": family_traffic("pixelnorm_act", "pixelnorm128"), "launches": vres.get("vae_pixelnorm_launches"),
+                    "avg_ms": vres["vae_kernel_breakdown_ms"]["pixelnorm_act"] / vres["vae_pixelnorm_launches"]}
         except ImportError:
             result["vae_decode_fps"] = None
 

@@ -105,9 +105,11 @@ int ltxk_gemm_bf16(const ltxk_gemm_args* args, void* stream);
  * INTEGER row offset, so bf16(P) does not depend on the tiling; l = sum P in fp32; O = bf16((bf16(P) @ V) / l).
  * ------------------------------------------------------------------------------------- */
 enum {
-  /* The query tiles of the short last round of workgroups are normally split over two workgroups that halve the keys
-   * and merge (O, M, l): faster, but those rows then sum their keys in another order than in a launch whose grid has no
-   * short round.  With this flag the result for a (batch, head) does not depend on how many share a launch.           */
+  /* Launches of fewer than 1.25 rounds of 128-row query tiles: the tiles of the short last round of workgroups are normally
+   * split over two workgroups that halve the keys and merge (O, M, l): faster, but those rows then sum their keys in another
+   * order than in a launch whose grid has no short round.  With this flag the result for a (batch, head) does not depend on
+   * how many share a launch.  Larger launches run a mixed grid of 192- and 128-row tiles that never splits keys: they have
+   * the flag's bits with or without it.                                                                                  */
   LTXK_ATTN_NO_TAIL_SPLIT = 1
 };
 typedef struct ltxk_attn_args {

@@ -657,8 +657,12 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
       }
     }
     // ---- online softmax per query block (key axis = registers x lane groups g) ----
+    // The deferral decision is taken per 16-row query block (one wave-uniform branch each), not per wave: a row's sequence of
+    // offsets M then depends only on its own MFMA block - the same 16 rows in every grid (tiles start at multiples of 64 rows) -
+    // and not on which other blocks share its wave.  (exp2(fma(S, c, -M)) is 2^-M exp2(S c) only up to the fp32 rounding of the
+    // fma, which depends on M: with a per-wave decision the 192-row and the 128-row forms differed by one bf16 ulp in a handful
+    // of rows whenever a wave-mate's spike raised M early.)
     float mxc[QB];
-    bool grow = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       float mx = s[0][qb][0];
@@ -667,12 +671,11 @@ __device__ __forceinline__ void fa_body16(const FaParams& p, char* smem, int bh,
 #pragma unroll
         for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[i][qb][j]);
       mxc[qb] = mx * p.c;                                   // this lane's keys only: enough for the deferral test (see fa_body)
-      grow |= mxc[qb] - mc_run[qb] > FA_DEFER;
     }
-    if (__any(grow)) {
-      asm volatile("" ::: "memory");
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
+      if (__any(mxc[qb] - mc_run[qb] > FA_DEFER)) {
+        asm volatile("" ::: "memory");
         const float m_new = fmaxf(mc_run[qb], __builtin_ceilf(lane_xor32_max(lane_xor16_max(mxc[qb]))));
         const float alpha = __builtin_amdgcn_exp2f(mc_run[qb] - m_new);
         mc_run[qb] = m_new;

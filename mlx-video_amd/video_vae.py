@@ -650,4 +650,8 @@ def bench_decode(dev, Fl: int, Hl: int, Wl: int, iters: int = 3) -> dict:
         out["vae_conv3d_tflops"] = cf["flops"] / (cf["ms"] * 1e-3) / 1e12
         out["vae_conv3d_launches"] = cf["launches"] // iters
         out["vae_kernel_breakdown_ms"] = {k: v_["ms"] / iters for k, v_ in fams.items()}
+    if "pixelnorm_act" in fams and fams["pixelnorm_act"]["ms"] > 0:          # the decoder's HBM-bound kernel (r + w of the volume)
+        pn = fams["pixelnorm_act"]
+        out["vae_pixelnorm_GBs"] = pn["bytes"] / (pn["ms"] * 1e-3) / 1e9
+        out["vae_pixelnorm_launches"] = pn["launches"] // iters
     return out

@@ -1,14 +1,18 @@
 """Per-launch-shape time of one DiT forward (eager launches, HIP events around every libltxk call), B=1 against B=2:
 which launches make the CFG-pair split (one B=1 forward per rank) less efficient than the B=2 forward.
-  python scripts/prof_forward_shapes.py [N] [layers]"""
+  python scripts/prof_forward_shapes.py [N | FxHxW] [layers] [batches, e.g. 1,2]
+N = 1280 / 3328: latent (N/256) x 16 x 16 (configs 2 / 4); FxHxW e.g. 9x12x12 (N=1296, configs 3 / 5 stage 1), 9x24x24 (N=5184, stage 2)"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mlx_video_amd import ops
 from mlx_video_amd.ltx_model import LTXModel, LTXModelConfig, TimestepPlan, precompute_freqs_cis
 from mlx_video_amd.schedulers import create_position_grid
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
+shape = sys.argv[1] if len(sys.argv) > 1 else "1280"
+Fl, Hl, Wl = (int(v) for v in shape.split("x")) if "x" in shape else (int(shape) // 256, 16, 16)
+N = Fl * Hl * Wl
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+BATCHES = tuple(int(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2)
 dev = torch.device("cuda:0")
 model = LTXModel.random_init(LTXModelConfig(num_layers=L), dev, seed=1234)
 rec = []
@@ -26,11 +30,11 @@ def fa(q, k, vt, out, B, H, Tq, Tk, scale, **kw):
 ops.gemm, ops.flash_attn = gemm, fa
 import mlx_video_amd.ltx_model as lm
 res = {}
-for B in (1, 2):
+for B in BATCHES:
     g = torch.Generator(device=dev).manual_seed(1)
     lat = torch.randn((B, N, 128), generator=g, device=dev).to(torch.bfloat16)
     ctx = torch.randn((B, 1024, 3840), generator=g, device=dev).to(torch.bfloat16)
-    pos = create_position_grid(1, N // 256, 16, 16).to(dev)
+    pos = create_position_grid(1, Fl, Hl, Wl).to(dev)
     pe = precompute_freqs_cis(pos, 4096, 10000.0, (20, 2048, 2048), 32)
     plan = TimestepPlan(torch.tensor([0.7], device=dev).to(torch.bfloat16), torch.zeros(B * N, dtype=torch.int32, device=dev))
     for it in range(3):
@@ -43,9 +47,12 @@ for B in (1, 2):
     for name, fl, s, e in rec:
         d = agg.setdefault(name, [0, 0.0, 0.0]); d[0] += 1; d[1] += s.elapsed_time(e) * 1e3; d[2] += fl
     res[B] = (agg, t0.elapsed_time(t1))
-for B in (1, 2):
+for B in BATCHES:
     agg, tot = res[B]
-    print(f"==== B={B}: forward {tot:.2f} ms (eager, instrumented), per block:")
+    print(f"==== N={N} B={B}: forward {tot:.2f} ms over {L} blocks (eager, instrumented), per block:")
+    tot_us = tot_fl = 0.0
     for name, (n, us, fl) in agg.items():
         if n >= L:
             print(f"  {name:48s} x{n // L:2d}/block  {us / n:8.1f} us  {fl / us / 1e6:7.1f} TF/s")
+            tot_us += us / L; tot_fl += fl / L
+    print(f"  GEMM + attention launches of one block: {tot_us:8.1f} us  {tot_fl / tot_us / 1e6:7.1f} TF/s")

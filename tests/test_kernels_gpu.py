@@ -403,3 +403,35 @@ def test_flash_attn_mfma_shapes_agree(dev, B, H, Tq, Tk, monkeypatch, ab_lib):
     torch.cuda.synchronize()
     for name in ("plain", "no_split", "qprep"):
         parity.auto(rel_l2(outs[("16", name)], outs[("32", name)]), 3e-4, tag=name)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 32, 1280, 1280), (2, 32, 1296, 1024), (1, 8, 200, 333), (3, 16, 777, 130), (4, 32, 640, 640), (2, 8, 2100, 64)])
+def test_flash_attn_query_blocks_per_wave_agree(dev, B, H, Tq, Tk, monkeypatch, ab_lib):
+    """Round 4: a launch is a mixed grid of 192-row tiles (three 16-row MFMA blocks per wave) and 128-row tiles (two), chosen per
+    shape (attention.hip, fa_pick_mix).  More rows per wave changes which K / V^T fragment feeds how many MFMAs, not the order in
+    which a row meets its keys: the mixed grid, 192-row tiles only (LTXK_FA_QB=3 in the A/B build) and the 128-row kernel without
+    its key-split tail (LTXK_FA_QB=2 + LTXK_ATTN_NO_TAIL_SPLIT) must agree BIT FOR BIT - plain and with the fused query
+    preparation, ragged query tiles (1296 = 6 x 192 + 144, 777, 200) and ragged key tiles."""
+    ops = _ops()
+    D = H * 128
+    g = torch.Generator(device=dev).manual_seed(B * 7 + H + Tq + Tk)
+    q = torch.randn((B * Tq, D), generator=g, device=dev).to(BF)
+    k = torch.randn((B * Tk, D), generator=g, device=dev).to(BF)
+    vt = torch.randn((B, D, (Tk + 63) // 64 * 64), generator=g, device=dev).to(BF)
+    ss = (q.float() ** 2).reshape(B * Tq, D // 64, 64).sum(-1).contiguous()
+    w = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(BF)
+    cos, sin = torch.randn((H, Tq, 64), generator=g, device=dev), torch.randn((H, Tq, 64), generator=g, device=dev)
+    outs = {}
+    # (tail_split=False throughout: below 1.25 rounds of 128-row tiles the default launch is the 128-row kernel, whose key-split
+    # tail is the one form with another summation order)
+    for form, env, ts in (("two_blocks", "2", False), ("mixed", "0", False), ("three_blocks", "3", False)):
+        monkeypatch.setenv("LTXK_FA_QB", env)
+        for name, kw in (("plain", {}), ("qprep", dict(q_sumsq=ss, q_norm_weight=w, cos=cos, sin=sin, eps=1e-6))):
+            o = torch.full((B * Tq + 1, D), 7.0, dtype=BF, device=dev)
+            ops.flash_attn(q, k, vt, o[:B * Tq], B, H, Tq, Tk, 1.0 / math.sqrt(128), tail_split=ts, **kw)
+            torch.cuda.synchronize()
+            assert bool((o[B * Tq:] == 7.0).all()), "wrote past the last query row"
+            outs[(form, name)] = o[:B * Tq]
+    for name in ("plain", "qprep"):
+        assert torch.equal(outs[("mixed", name)], outs[("two_blocks", name)]), f"mixed grid vs 128-row tiles ({name})"
+        assert torch.equal(outs[("three_blocks", name)], outs[("two_blocks", name)]), f"192-row tiles vs 128-row tiles ({name})"
