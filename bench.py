@@ -129,10 +129,10 @@ def family_traffic(family: str, prefer: str):
     t = {"bytes_per_launch": k["bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
          "traffic_over_algorithmic": k["bytes_per_launch"] / k["algorithmic_bytes"], "kernel": f"{k.get('kernel')} [{k.get('shape')}]",
          "source_sha": source_sha(), "source": f"profiles/{fname} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 / WRITE_SIZE, separate passes)"}
-    by = {n: v for n, v in fam.items() if "mfma_busy_frac_of_simd_cycles" in v}
+    by = {n: v for n, v in fam.items() if v.get("mfma_busy_frac_of_simd_cycles")}
     if by:
         t["mfma_busy_frac_by_shape"] = {n: round(v["mfma_busy_frac_of_simd_cycles"], 3) for n, v in by.items()}
-        t["clock_GHz_by_shape"] = {n: round(v["clock_GHz_profiled"], 2) for n, v in by.items()}
+        t["clock_GHz_by_shape"] = {n: round(v["clock_GHz_profiled"], 2) for n, v in by.items() if v.get("clock_GHz_profiled")}
         t["traffic_over_algorithmic_by_shape"] = {n: round(v["bytes_per_launch"] / v["algorithmic_bytes"], 2) for n, v in fam.items()}
     return t
 

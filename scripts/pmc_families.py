@@ -16,7 +16,7 @@ D = 4096
 
 def attn_case(Tq, Tk, B=2, H=32):
     tkp = (Tk + 63) // 64 * 64
-    return {"family": "flash_attn", "driver": ["prof_family.py", f"attn_{Tq}x{Tk}" + ("_b1" if B == 1 else "")], "match": "flash_attn16_kernel",
+    return {"family": "flash_attn", "driver": ["prof_family.py", f"attn_{Tq}x{Tk}" + ("_b1" if B == 1 else "")], "match": "flash_attn16_",
             "flops": 4.0 * B * H * Tq * Tk * 128, "algorithmic_bytes": 2.0 * B * D * (2 * Tq + Tk + tkp),
             "shape": f"B={B} H={H} Tq={Tq} Tk={Tk} dh=128"}
 
@@ -88,7 +88,8 @@ for name, c in CASES.items():
         e["traffic_over_algorithmic"] = e["bytes_per_launch"] / c["algorithmic_bytes"]
     if "GRBM_GUI_ACTIVE" in vals and vals.get("avg_ns"):
         cyc = vals["GRBM_GUI_ACTIVE"] / 8.0                                  # summed over the 8 XCDs
-        e["clock_GHz_profiled"] = cyc / vals["avg_ns"]
+        if vals["avg_ns"] >= 30000:          # (short launches: the un-profiled trace duration and the profiled cycle count do not describe the same run)
+            e["clock_GHz_profiled"] = cyc / vals["avg_ns"]
         e["mfma_busy_frac_of_simd_cycles"] = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * cyc)
         w = vals["SQ_WAVE_CYCLES"]
         e["wave_cycle_split"] = {"parked_WAIT_ANY": vals["SQ_WAIT_ANY"] / w, "issue_stalled_WAIT_INST_ANY": vals["SQ_WAIT_INST_ANY"] / w,
