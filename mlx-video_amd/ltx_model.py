@@ -144,6 +144,9 @@ class LTXModel:
         # rank == row b of the B=2 cfg_batch forward), at ~5 % of attention time at N=1280 (attention.hip)
         self.attn_tail_split = True
         self._pack(weights)
+        # the split-K scratch of ops.gemm (small-M launches) must exist before anyone captures a forward into a hipGraph: allocated
+        # inside a capture it would come from that graph's private pool
+        ops._gemm_workspace(self.tables.device)
 
     # ------------------------------------------------------------------ weights
     def _pack(self, W: Dict[str, torch.Tensor]) -> None:

@@ -11,15 +11,20 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 H, D = 32, 4096
 SHAPES = [(2, 1024, 1280), (2, 1536, 1280), (2, 1280, 1280), (2, 1280, 1024), (2, 1296, 1296), (2, 1296, 1024), (2, 5184, 5184), (2, 5184, 1024), (2, 3328, 3328), (2, 3328, 1024),
           (1, 1280, 1280), (1, 1280, 1024), (1, 1296, 1296), (1, 3328, 3328), (1, 5184, 5184), (1, 5184, 1024), (2, 320, 320), (2, 640, 640), (4, 1280, 1280)]
-with _lib.use_library(_lib.AB_LIB_PATH):
+ALT = os.environ.get("AB_ALT_LIB")           # optional second build of the library: its mixed grid runs as variant "0alt"
+alt = _lib._open(ALT) if ALT else None
+if os.environ.get("AB_SHAPES"):
+    SHAPES = [tuple(int(v) for v in s_.split(":")) for s_ in os.environ["AB_SHAPES"].split()]
+with _lib.use_library(_lib.AB_LIB_PATH) as main_lib:
     for B, Tq, Tk in SHAPES:
         g = torch.Generator(device=dev).manual_seed(Tq + Tk)
         q = torch.randn((B * Tq, D), generator=g, device=dev).to(torch.bfloat16)
         k = torch.randn((B * Tk, D), generator=g, device=dev).to(torch.bfloat16)
         vt = torch.randn((B, D, (Tk + 63) // 64 * 64), generator=g, device=dev).to(torch.bfloat16)
         outs, graphs = {}, {}
-        for qb, ts in (("2", True), ("2nosplit", False), ("3", True), ("0mix", True)):
+        for qb, ts in (("2", True), ("2nosplit", False), ("3", True), ("0mix", True)) + ((("0alt", True),) if alt else ()):
             os.environ["LTXK_FA_QB"] = qb[0]
+            _lib._lib = alt if qb == "0alt" else main_lib
             out = torch.zeros((B * Tq, D), dtype=torch.bfloat16, device=dev)
             fn = lambda o=out, t=ts: ops.flash_attn(q, k, vt, o, B, H, Tq, Tk, 1 / math.sqrt(128), tail_split=t)
             fn(); torch.cuda.synchronize()
@@ -29,7 +34,8 @@ with _lib.use_library(_lib.AB_LIB_PATH):
                 with torch.cuda.graph(gr, stream=st):
                     for _ in range(20): fn()
             graphs[qb] = gr
-        same = torch.equal(outs["3"], outs["2nosplit"]) and torch.equal(outs["0mix"], outs["2nosplit"])
+        _lib._lib = main_lib
+        same = torch.equal(outs["3"], outs["2nosplit"]) and torch.equal(outs["0mix"], outs["2nosplit"]) and (alt is None or torch.equal(outs["0alt"], outs["2nosplit"]))
         ts = {n: [] for n in graphs}
         for r in range(rounds):
             for n, gr in graphs.items():
