@@ -407,9 +407,11 @@ class LTXModel:
             # V^T transposed.  k is normalised + rotated in place; q stays RAW in HBM - the attention kernel normalises
             # and rotates its Q fragments in registers (attention.py:129-136).
             ops.rmsnorm_modulate(x, eps, mod[:, 1], mod[:, 0], ms, tok2row, out=nx, sumsq=s_x, scale_is_one_plus=bool(fs))
-            # (fuse bit 8: q|k on the 320x256 tile with v as its own launch - a gain at M=2560 only; at small M every launch is a
-            # weight stream with ~5 us of fixed cost, so q|k|v stays ONE launch there)
-            if fq and (not (self.fuse & 8) or M <= ops.SPLITK_MAX_M):
+            # (fuse bit 8: q|k on the 320x256 tile with v as its own launch - a gain only where M is a whole number of 320-row
+            # tiles (M=1280: 35.4 against 35.6 ms per forward, M=2560: 60.3 against 61.0); every other row count is 1-4 % faster
+            # with q|k|v as ONE launch (M=1296: 39.4 against 41.2 ms, 3328: 87.6 / 89.2, 5184: 141.5 / 143.8, 6656: 161.5 / 164.7;
+            # scripts/exp_qkv_one_launch.py), and at small M every launch is a weight stream with ~5 us of fixed cost)
+            if fq and (not (self.fuse & 8) or M <= ops.SPLITK_MAX_M or M % 320 != 0):
                 ops.gemm(nx, blk.wqkv, blk.bqkv, out=qk, out2=vt, n_split=2 * D, out_tokens_per_batch=N, sumsq=s_qk)
             else:
                 ops.gemm(nx, blk.wqkv[:2 * D], blk.bqkv[:2 * D], out=qk, sumsq=s_qk)
