@@ -2,9 +2,11 @@
 // Replaces mx.fast.scaled_dot_product_attention (attention.py:47) and the head reshapes
 // around it (attention.py:24-33,50-51).
 //
-// Two kernels of the same structure live here: flash_attn16_kernel on v_mfma_f32_16x16x32_bf16 (fa_body16, round 3, the
-// one ltxk_flash_attn launches) and flash_attn_kernel on v_mfma_f32_32x32x16_bf16 (fa_body, rounds 1-2; kept for the A/B
-// build, LTXK_FA_MFMA=32).  The 32x32 form is described first; fa_body16's header has the 16x16 operand map.
+// Kernels of the same structure live here.  On v_mfma_f32_16x16x32_bf16 (fa_body16<KS, QB>, rounds 3-4; its header has the operand
+// map): flash_attn16_mix_kernel - 192-row tiles (three 16-row query blocks per wave) mixed with 128-row tiles, what
+// ltxk_flash_attn launches from 1.25 rounds of 128-row tiles up - and flash_attn16_kernel - 128-row tiles with a key-split tail,
+// for smaller grids.  On v_mfma_f32_32x32x16_bf16: flash_attn_kernel (fa_body, rounds 1-2; kept for the A/B build,
+// LTXK_FA_MFMA=32), described first.
 //
 // Structure (gfx950): workgroup = 4 waves, each wave owns 32 query rows; K/V tiles of 64 keys
 // are staged by LDS-DMA (global_load_lds_dwordx4) into a 2-deep LDS ring, one barrier per tile.
