@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn16_kernel(FaParams p) {
 // Query blocks per wave (round 4).  With 16-row MFMA blocks a wave can own two blocks (32 rows, 128-row workgroups: the kernel
 // above) or three (48 rows, 192-row workgroups): every K / V^T fragment read then feeds three MFMAs instead of two, and a workgroup
 // stages its K / V^T tiles for 1.5x the rows - measured 12 % cheaper per query row at equal fill (one full round of 512 workgroups:
-// Tq=1536 in 62.4 us against Tq=1024 in 47.6 us at Tk=1280, B=2, H=32; 5184^2: 700 against 772 us = 1.26 PF/s;
+// Tq=1536 in 60.7 us against Tq=1024 in 46.5 us at Tk=1280, B=2, H=32; 5184^2: 702 against 781 us = 1.25 PF/s;
 // profiles/r04_attn_qb_ab.log), at 256 registers per lane with one K fragment set instead of two.  Four blocks need more than the
 // 256 registers two waves per SIMD leave each (o alone is 128).  What a grid of 192-row tiles loses is balance: N=1280 is 6.67 of
 // them.  So ONE launch mixes the two sizes: per (batch, head) `qta` tiles of 192 rows followed by `qtb` tiles of 128 rows, chosen by
@@ -935,9 +935,9 @@ extern "C" int ltxk_flash_attn(const ltxk_attn_args* a, void* stream) {
   // More than one 128-row tile per (batch, head): the mixed 192 / 128-row grid (flash_attn16_mix_kernel).  A/B build: LTXK_FA_QB=2
   // keeps the 128-row kernel with its tail split everywhere, 3 forces 192-row tiles only.
   // Which grid (same box, interleaved, B*H = 32 / 64 / 128; profiles/r04_attn_qb_ab.log): from 1.25 rounds of 128-row tiles up the
-  // mixed grid wins by 9-15 % (1280^2 B=2: 56.8 -> 49.7 us, 1296^2: 68.4 -> 57.8, 5184^2: 772 -> 702, B=4 1280^2: 108 -> 98); below
+  // mixed grid wins by 8-15 % (1280^2 B=2: 58.8 -> 50.0 us, 1296^2: 68.8 -> 59.3, 5184^2: 781 -> 701, B=4 1280^2: 113.5 -> 102.4); below
   // that the chip has fewer workgroups than slots, a CU runs one workgroup - one wave per SIMD, ~0.8 of the shared rate - and the
-  // 128-row kernel's key-split tail, which doubles the workgroups, is the faster form (B=1 1280^2: 32.7 against 35.5 us).
+  // 128-row kernel's key-split tail, which doubles the workgroups, is the faster form (B=1 1280^2: 33.7 against 37.4 us for 192-row tiles).
   const int qb_env = LTXK_AB_INT("LTXK_FA_QB", 0);
   const long tiles128 = (long)((Tq + 127) / 128) * B * H;
   if (Tq > 128 && qb_env != 2 && (qb_env == 3 || 4 * tiles128 >= 5L * slots) && LTXK_AB_INT("LTXK_FA_MFMA", FA_DEFAULT_MFMA) == 16) {
