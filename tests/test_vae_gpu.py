@@ -277,6 +277,17 @@ def test_lora_merge(dev):
     torch.cuda.synchronize()
     ref = O.BF16.r(w.float() + O.BF16.r(0.7 * (B.float() @ A.float())))
     assert float((merged.float().cpu() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max())
+    # a LoRA stored as F32 / F16 (lora.py:114 multiplies B @ A in fp32 from the STORED dtype): this implementation feeds the matrix
+    # cores bf16 operands - the stated deviation of lora._pack_group, pinned here: the merge equals the reference formula
+    # evaluated on the bf16-rounded factors, and stays within 3 bf16 ulps of the delta of the formula on the fp32 factors
+    A32, B32 = torch.randn(16, 128, generator=g) * 0.1, torch.randn(256, 16, generator=g) * 0.1
+    sd32 = {k: v for k, v in zip(sd, (A32, B32))}
+    m32 = apply_lora_to_weights(Wd, [spec], lora_states={"mem": sd32})["transformer_blocks.0.attn1.to_out.weight"].float().cpu()
+    torch.cuda.synchronize()
+    ref_bf = O.BF16.r(w.float() + O.BF16.r(0.7 * (B32.to(BF).float() @ A32.to(BF).float())))
+    assert float((m32 - ref_bf).abs().max()) <= 2.0 ** -8 * float(ref_bf.abs().max())
+    delta32 = 0.7 * (B32 @ A32)
+    assert float((m32 - (w.float() + delta32)).abs().max()) <= 3 * 2.0 ** -8 * float(delta32.abs().max()) + 2.0 ** -8 * float(w.float().abs().max())
 
 
 def test_on_frames_ready_covers_89_frames(dev):
