@@ -176,8 +176,13 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
                    upsampler=None, prompt_embeds: Optional[torch.Tensor] = None,
                    negative_prompt_embeds: Optional[torch.Tensor] = None, text_encoder: Optional[Callable] = None,
                    noise_fn: Optional[Callable] = None, device=None, on_frames_ready: Optional[Callable] = None,
-                   return_latents: bool = False, stage2_lora_in_place: Optional[bool] = None) -> np.ndarray:
-    """See the module docstring.  Returns uint8 frames (F,H,W,3) (generate.py:4195-4197)."""
+                   return_latents: bool = False, stage2_lora_in_place: Optional[bool] = None,
+                   hoist_context: bool = False) -> np.ndarray:
+    """See the module docstring.  Returns uint8 frames (F,H,W,3) (generate.py:4195-4197).
+    ``hoist_context`` (not in the reference, off by default): the part of the forward that depends on the text context only -
+    caption projection and the 48 cross-attention K / V^T projections, 3.37 TFLOP that the reference recomputes in every forward
+    (ltx.py:77-89, attention.py:123-126) - is computed once per denoise call and reused by every step: the same kernels on the
+    same inputs, hence the same latents bit for bit, 8-10 % less work per dev step at 512x512x33."""
     t_start = time.perf_counter()
     if isinstance(pipeline, str):
         pipeline = PipelineType(pipeline)
@@ -286,7 +291,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         latents = state1.latent if state1 is not None else noise_fn(shape1)
         with timer.phase("stage1_denoise"):
             latents, _ = denoise_distilled(latents, pos1, ctx_pos, transformer, sig1, state=state1,
-                                           compile_step=compile_step, fp32_euler=fp32_euler, use_graph=compile_step)
+                                           compile_step=compile_step, fp32_euler=fp32_euler, use_graph=compile_step, cache_context=hoist_context)
         with timer.phase("upsample"):
             from .upsampler import upsample_latents
             latents = upsample_latents(latents, upsampler, vae_decoder.latents_mean, vae_decoder.latents_std)
@@ -314,10 +319,10 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         with timer.phase("stage2_denoise"):
             if stage2_dev:
                 latents = denoise_dev(latents, pos2, ctx_pos, ctx_neg, tr2, torch.tensor(sig2), cfg_scale=cfg_scale,
-                                      state=state2, compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step)
+                                      state=state2, compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step, cache_context=hoist_context)
             else:
                 latents, _ = denoise_distilled(latents, pos2, ctx_pos, tr2, sig2, state=state2, compile_step=compile_step,
-                                               fp32_euler=fp32_euler, use_graph=compile_step)
+                                               fp32_euler=fp32_euler, use_graph=compile_step, cache_context=hoist_context)
     else:
         lh, lw = height // 32, width // 32
         n_tok = latent_frames * lh * lw
@@ -332,7 +337,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         latents = state.latent if state is not None else noise_fn(shape)
         with timer.phase("dev_denoise"):
             latents = denoise_dev(latents, pos, ctx_pos, ctx_neg, transformer, sigmas, cfg_scale=cfg_scale, state=state,
-                                  compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step)
+                                  compile_step=compile_step, cfg_batch=cfg_batch, use_graph=compile_step, cache_context=hoist_context)
 
     if return_latents:
         return latents
@@ -456,6 +461,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--no-compile", action="store_true", help="Disable the compiled step even if LTX_COMPILE enables it")
     ap.add_argument("--cfg-batch", action="store_true", default=False, help="CFG pair as one B=2 forward")
     ap.add_argument("--no-cfg-batch", action="store_true", help="Two sequential forwards even if LTX_CFG_BATCH enables batching")
+    ap.add_argument("--hoist-context", action="store_true",
+                    help="(not in the reference CLI) compute the text-only part of the forward once per denoise call instead of in every step; same latents")
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--profile-json", type=str, default=None)
     ap.add_argument("--prompt-embeds", type=str, default=None, help=".pt/.npy file with (1,1024,3840) text embeddings")
@@ -538,7 +545,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     generate_video(model_repo=args.model_repo, prompt=args.prompt, pipeline=PipelineType(args.pipeline),
                    negative_prompt=args.negative_prompt, height=args.height, width=args.width, num_frames=args.num_frames,
                    num_inference_steps=args.steps, cfg_scale=args.cfg_scale, seed=args.seed, fps=args.fps,
-                   output_path=args.output_path, tiling=args.tiling, compile_step=args.compile_step, cfg_batch=args.cfg_batch,
+                   output_path=args.output_path, tiling=args.tiling, compile_step=args.compile_step, cfg_batch=args.cfg_batch, hoist_context=args.hoist_context,
                    eval_interval=args.eval_interval,
                    profile=args.profile, profile_json_path=args.profile_json, stage1_steps=args.stage1_steps,
                    stage2_steps=args.stage2_steps, sigma_subsample=args.sigma_subsample, verbose=True, device=dev,

@@ -108,6 +108,11 @@ def test_two_stage_pipelines_run(dev, pipe):
                             upsampler=m["upsampler"], prompt_embeds=emb, device=dev, seed=3, **kw)
     assert frames.shape == (9, 128, 128, 3) and frames.dtype == np.uint8
     assert 5 < frames.mean() < 250
+    # hoist_context: the text-only part of the forward computed once per denoise call - the same kernels on the same inputs
+    hoisted = generate_video(prompt="x", pipeline=PipelineType(pipe), height=128, width=128, num_frames=9, stage1_steps=2,
+                             stage2_steps=1, transformer=m["transformer"], vae_decoder=m["vae_decoder"], vae_encoder=m["vae_encoder"],
+                             upsampler=m["upsampler"], prompt_embeds=emb, device=dev, seed=3, hoist_context=True, **kw)
+    assert np.array_equal(hoisted, frames)
 
 
 def test_pipeline_surface_and_errors(dev):
