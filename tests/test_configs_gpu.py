@@ -214,6 +214,23 @@ def test_temporal_tiled_decode_97_frames_vs_oracle(dev):
     parity.check("vae.temporal_tiled_decode_97f.video_vs_oracle_tiling", rel_l2(out.float(), ref), 1.6e-2)
 
 
+def test_temporal_tiled_decode_97_frames_full_size_vs_oracle(dev):
+    """The same policy on config 4's real latent (13 x 16 x 16 -> 97 x 512 x 512) with the decoder's real depth: three
+    temporal tiles of 64 frames blended over 24-frame ramps (tiling.py:279-509), against the oracle's tiling of its own decodes
+    (~50 s of CPU oracle; measured 1.34e-2 - the full-size single decode's 1.39e-2, i.e. tiling adds nothing)."""
+    from mlx_video_amd.video_vae import LTX2VideoDecoder, TilingConfig
+    tc = TilingConfig.auto(512, 512, 97)
+    W = OV.make_decoder_weights(seed=5, layers_per_block=5)
+    dec = LTX2VideoDecoder({k: v.to(dev) for k, v in W.items()}, num_layers_per_block=5)
+    g = torch.Generator().manual_seed(8)
+    lat = torch.randn(1, 128, 13, 16, 16, generator=g).to(BF)
+    out = dec.decode_tiled(lat.to(dev), tiling_config=tc, tiling_mode="temporal").float().cpu()
+    torch.cuda.synchronize()
+    assert out.shape == (1, 3, 97, 512, 512)
+    ref = OV.decode_with_tiling(lambda z: OV.vae_decode(z, W, O.BF16, layers_per_block=5), lat.float(), None, 0, 64, 24, O.BF16)
+    parity.check("vae.temporal_tiled_decode_97f_full_size.video_vs_oracle_tiling", rel_l2(out, ref), 2e-2)
+
+
 def test_spatial_tiled_decode_768_vs_oracle(dev):
     """Config 3/5's decode policy: TilingConfig.auto(768,768,65) = 384 px tiles, 64 px overlap, no temporal tiling.
     Latent 24x24 (768x768 px, 3x3 tiles) with ONE latent frame (the tile geometry is what is under test)."""
