@@ -304,6 +304,22 @@ def test_default_encoder_blocks_vs_oracle(dev):
     parity.check("vae.default_encoder_9x64x64.latent_vs_oracle", rel_l2(z.float(), ref), 2.5e-2)
 
 
+def test_default_encoder_full_size_vs_oracle(dev):
+    """The same encoder on a FULL-SIZE conditioning clip: 33 x 512 x 512 -> latent 5 x 16 x 16 (the clip an image / video
+    conditioning of config 2 goes through, video_vae.py:321-372): 26 causal convolutions with zero spatial padding, four
+    space-to-depth stages with their group-mean skips, PixelNorm + SiLU, the per-channel normalisation."""
+    from mlx_video_amd.video_vae import VideoEncoder
+    W = OV.make_encoder_weights(seed=23)
+    enc = VideoEncoder({k: v.to(dev) for k, v in W.items()})
+    g = torch.Generator().manual_seed(24)
+    vid = (torch.rand(1, 3, 33, 512, 512, generator=g) * 2 - 1).to(BF)
+    z = enc(vid.to(dev))
+    torch.cuda.synchronize()
+    assert z.shape == (1, 128, 5, 16, 16)
+    ref = OV.vae_encode(vid.float(), W, O.BF16)
+    parity.check("vae.default_encoder_33x512x512.latent_vs_oracle", rel_l2(z.float(), ref), 2.5e-2)
+
+
 # ---------------------------------------------------------------------------------------------------- (e) LoRA merge, full size
 @pytest.mark.parametrize("rank", [64, 128])
 def test_lora_merge_4096(dev, rank):
