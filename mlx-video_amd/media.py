@@ -88,7 +88,9 @@ def resize_area(frames: np.ndarray, height: int, width: int) -> np.ndarray:
     """cv2.resize(frame, (width, height), interpolation=cv2.INTER_AREA) for every frame of an (F,H,W,C) array
     (utils.py:597-598 on the decoded uint8 frames, utils.py:699-705 on float frames): horizontal pass then vertical pass
     in fp32; uint8 input gives uint8 output, rounded to nearest-even as cv2's saturate_cast does.  (One filter for every
-    container a conditioning clip can arrive in: tensors take the same table through ltxk_resize_area.)"""
+    container a conditioning clip can arrive in: tensors take the same table through ltxk_resize_area.)  Each axis follows
+    its own rule; a resize that shrinks one axis and enlarges the other goes through cv2's linear path for BOTH axes there -
+    not reproduced (conditioning resizes keep the aspect; parity unpinned like every fractional factor)."""
     F, H, W, C = frames.shape
     tx = area_taps(W, width) if W != width else None
     ty = area_taps(H, height) if H != height else None
