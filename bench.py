@@ -246,6 +246,13 @@ def visible_gpu_count() -> int:
         return -1
     if n == 0:
         return -1
+    # a container that was handed some of the host's GPUs still sees the whole topology; the render nodes it can open are its own
+    try:
+        rn = len(glob.glob("/dev/dri/renderD*"))
+        if rn > 0:
+            n = min(n, rn)
+    except OSError:
+        pass
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
