@@ -289,7 +289,11 @@ def test_gemm_split_k_form(dev, M, N, K, S, monkeypatch, ab_lib):
         rms = r.float().pow(2).mean().sqrt()
         ulp = torch.maximum(r.float().abs(), rms / 64).log2().floor().exp2() * 2.0 ** -7
         ulp_big = torch.maximum(r.float().abs(), rms).log2().floor().exp2() * 2.0 ** -7
-        assert float((d > ulp * 1.001).float().mean()) <= 2e-3 and float((d / ulp_big).max()) <= 2.001, \
+        # (an activation maps a one-ulp flip of y near a binade boundary - ulp(y) = 2^-7 just above 1.0, gelu(1.0) = 0.84 has
+        # ulp 2^-8 - onto up to 3 ulps of its output: seen on < 0.005 % of GELU outputs in scripts/fuzz_gemm_forms.py)
+        # and the gate multiplies it: bf16(y * gate) moves by |gate| ulps of y when y flips by one (synthetic gates reach ~4)
+        worst_ulps = 3.001 if name.startswith(("epi1", "epi2")) else (2.001 * max(1.0, float(gate.abs().max())) if name.startswith("epi3") else 2.001)
+        assert float((d > ulp * 1.001).float().mean()) <= 2e-3 and float((d / ulp_big).max()) <= worst_ulps, \
             f"{name}: beyond 1 ulp on {float((d > ulp * 1.001).float().mean()):.2%}, max {float((d / ulp_big).max()):.1f} ulp"
         worst = max(worst, float((x.float() - r.float()).norm() / r.float().norm()))
     parity.auto(worst, 3e-3)
