@@ -116,3 +116,23 @@ def test_bench_n2_code_path_rehearsal():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
     assert res["cfgpair"].get("finite") is True and res["cfgpair"]["pairs"] == 1, res["cfgpair"]
+
+
+def test_bench_under_torchrun_one_rank_over_rccl():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 ...`: the launcher form the driver uses, with the REAL
+    backend - init_process_group("nccl", device_id=...) is RCCL on ROCm - on this box's one GPU: process-group start-up, the barriers
+    and the MAX all_reduce of the timed region, teardown.  (What a one-GPU box can execute of the RCCL path; pair groups and the
+    all_gather need two devices: test_cfg_pair_hip_two_gpus_rccl.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "LTXK_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--layers", "2", "--steps", "2",
+                        "--warmup", "1", "--no-vae", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["parallelism"] == "seeds1"
