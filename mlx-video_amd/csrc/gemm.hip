@@ -1182,7 +1182,7 @@ extern "C" int ltxk_gemm_bf16(const ltxk_gemm_args* a, void* stream) {
       const long tiles = ((long)(a->M + 32 * tt2 - 1) / (32 * tt2)) * ((a->N + 127) / 128);
       const long have = ((long)p.RT * p.CT);
       if (ks_env >= 2) S = ks_env;
-      else if (tiles <= 160 && have <= 200 && (long)a->N * a->K >= (1L << 21)) {     // a real weight stream (>= 4 MB) the tiling cannot spread
+      else if (tiles <= 160 && have <= 240 && (long)a->N * a->K >= (1L << 21)) {     // a real weight stream (>= 4 MB) the tiling cannot spread well (have: its workgroups unsplit - up to 240 small LDS-bound tiles, M=640 FF2)
         S = (int)((256 + tiles / 2) / tiles);
         const int cap = a->K / (4 * a->M);
         if (S > cap) S = cap;

@@ -141,20 +141,30 @@ __global__ void latent_norm_cf_kernel(const bf16* __restrict__ x, int ldx, const
 // video (B,C,D,H*P,W*P) channels-first.   patchify (ops.py:9-44) is the inverse, with the
 // channel axis zero-padded to Cpad for the first convolution.
 // ---------------------------------------------------------------------------------------
+// One thread = the P output pixels of one patch row: P strided 2-byte reads inside one voxel's channel row, ONE P*2-byte store
+// (P = 4: 8 bytes; consecutive threads write consecutive pixels - whole lines per wave; one element per thread ran at 0.9 TB/s).
 __global__ void unpatchify_cf_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int B, int D, int H, int W,
                                      int C, int P) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int Ho = H * P, Wo = W * P;
-  const int64_t total = (int64_t)B * C * D * Ho * Wo;
+  const int Ho = H * P;
+  const int64_t total = (int64_t)B * C * D * Ho * W;
   if (idx >= total) return;
   int64_t r = idx;
-  const int xo = r % Wo; r /= Wo;
+  const int w = r % W; r /= W;
   const int yo = r % Ho; r /= Ho;
   const int d = r % D; r /= D;
   const int c = r % C;
   const int b = r / C;
-  const int ch = (c * P + (xo % P)) * P + (yo % P);
-  out[idx] = x[((((int64_t)b * D + d) * H + yo / P) * W + xo / P) * (C * P * P) + ch];
+  const bf16* src = x + ((((int64_t)b * D + d) * H + yo / P) * W + w) * (C * P * P) + c * P * P + (yo % P);
+  bf16* dst = out + idx * P;
+  if (P == 4) {
+    bf16x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = src[j * 4];
+    *(bf16x4*)dst = v;
+  } else {
+    for (int j = 0; j < P; ++j) dst[j] = src[j * P];
+  }
 }
 
 __global__ void patchify_cl_kernel(const bf16* __restrict__ vid, bf16* __restrict__ out, int B, int C, int D, int H, int W,
@@ -479,7 +489,8 @@ extern "C" int ltxk_latent_norm_cf(const void* x, int32_t ldx, const void* mean,
 extern "C" int ltxk_unpatchify_cf(const void* x, void* out, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
                                   int32_t P, void* stream) {
   LTXK_CHECK_ARG(x && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && P > 0, "ltxk_unpatchify_cf: bad arguments");
-  const int64_t total = (int64_t)B * C * D * H * P * W * P;
+  LTXK_CHECK_ARG(P != 4 || ((uintptr_t)out & 7) == 0, "ltxk_unpatchify_cf: out must be 8-byte aligned");
+  const int64_t total = (int64_t)B * C * D * H * P * W;
   hipLaunchKernelGGL(unpatchify_cf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16*)x, (bf16*)out, B, D, H, W, C, P);
   LTXK_CHECK_LAUNCH("ltxk_unpatchify_cf");
