@@ -176,7 +176,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
                    upsampler=None, prompt_embeds: Optional[torch.Tensor] = None,
                    negative_prompt_embeds: Optional[torch.Tensor] = None, text_encoder: Optional[Callable] = None,
                    noise_fn: Optional[Callable] = None, device=None, on_frames_ready: Optional[Callable] = None,
-                   return_latents: bool = False, stage2_lora_in_place: Optional[bool] = None,
+                   return_latents: bool = False, lora_in_place: Optional[bool] = None,
                    hoist_context: bool = False) -> np.ndarray:
     """See the module docstring.  Returns uint8 frames (F,H,W,3) (generate.py:4195-4197).
     ``hoist_context`` (not in the reference, off by default): the part of the forward that depends on the text context only -
@@ -228,10 +228,11 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         merged = apply_lora_to_weights(transformer_weights, [LoraSpec(Path(pth), float(st)) for pth, st in lora_list], verbose=verbose)
         return LTXModel(transformer_config or (transformer.config if transformer is not None else LTXModelConfig()), merged)
 
-    # stage-2 distilled LoRAs may be merged INTO the stage-1 model when nobody needs its un-merged weights again: by default
-    # only when the weights are loaded here (this call owns them); a caller that passes its own model opts in explicitly
-    if stage2_lora_in_place is None:
-        stage2_lora_in_place = transformer is None and transformer_weights is None
+    # LoRAs may be merged INTO the model when nobody needs its un-merged weights again (`loras` alone: one merged model serves every
+    # stage; `distilled_loras` alone: the stage-1 model is dead when stage 2 starts): by default only when the weights are loaded
+    # here (this call owns them); a caller that passes its own model opts in explicitly
+    if lora_in_place is None:
+        lora_in_place = transformer is None and transformer_weights is None
     if transformer is None and transformer_weights is None:
         if model_repo is None:
             raise FileNotFoundError("no transformer: pass transformer= or a local model_repo directory with LTX-2 safetensors")
@@ -242,7 +243,18 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         vae_decoder = vae_decoder or mods["vae_decoder"]
         vae_encoder, upsampler = vae_encoder or mods.get("vae_encoder"), upsampler or mods.get("upsampler")
     if loras:
-        transformer = _with_loras(loras, "loras")                  # stage 1 / dev: base + loras
+        if lora_in_place and not distilled_loras:
+            # nobody needs the un-merged weights again (stage 2 of a two-stage pipeline runs the same merged model): merge into the
+            # model's own panels instead of building a second 21-GB copy (0.5 s of first-touch allocation, 17 GB of HBM)
+            if transformer_weights is None:
+                raise ValueError("loras were given but the base transformer weights are not reachable: pass transformer_weights= "
+                                 "(the dict the transformer was built from) or a model_repo")
+            from .lora import LoraSpec, apply_lora_to_weights
+            if transformer is None:
+                transformer = LTXModel(transformer_config or LTXModelConfig(), transformer_weights)
+            apply_lora_to_weights(transformer.weight_views(), [LoraSpec(Path(pth), float(st)) for pth, st in loras], verbose=verbose, in_place=True)
+        else:
+            transformer = _with_loras(loras, "loras")              # stage 1 / dev: base + loras
     elif transformer is None:
         transformer = LTXModel(transformer_config or LTXModelConfig(), transformer_weights)
     if vae_decoder is None:
@@ -298,7 +310,7 @@ def generate_video(model_repo: Optional[str] = None, text_encoder_repo: Optional
         tr2 = stage2_transformer or transformer
         if distilled_loras:                                          # generate.py:3229-3237: base + distilled LoRAs only
             with timer.phase("stage2_transformer_load"):
-                if stage2_lora_in_place and not loras:
+                if lora_in_place and not loras:
                     # the stage-1 model IS the base model and is not used again: merge into its own panels (same EPI_SCALE_RES
                     # launches with the output aliasing the residual, same bits) instead of building a second 21-GB replica
                     from .lora import LoraSpec, apply_lora_to_weights

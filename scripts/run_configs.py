@@ -66,13 +66,19 @@ runs = [
     ("config1 dev 128x128x9 1 step", dict(pipeline=PipelineType.DEV, height=128, width=128, num_frames=9, num_inference_steps=1)),
     ("config2 dev 512x512x33 40 steps CFG4", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=33, num_inference_steps=40)),
     ("config4 (one seed) dev 512x512x97 40 steps CFG4, temporal-tiled decode", dict(pipeline=PipelineType.DEV, height=512, width=512, num_frames=97, num_inference_steps=40, tiling="temporal")),
-    ("config5 ic_lora 768x768x65 video-cond, merged LoRA (rank 64)", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
-                                                 loras=[(lora64, 1.0)],
+    ("config5 ic_lora 768x768x65 video-cond, LoRA (rank 64) merged IN PLACE into a fresh model", dict(pipeline=PipelineType.IC_LORA, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 loras=[(lora64, 1.0)], lora_in_place=True, fresh_model=True,
                                                  video_conditionings=[((torch.rand((1, 3, 65, 768, 768), generator=g, device=dev) * 2 - 1).to(BF), 0, 1.0)])),
-    ("config3 distilled 768x768x65 two-stage + 2x upsampler, distilled LoRA (rank 64) merged IN PLACE into the stage-1 model for stage 2 (run last: it consumes the model)", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
-                                                 distilled_loras=[(lora64, 0.8)], stage2_lora_in_place=True)),
+    ("config3 distilled 768x768x65 two-stage + 2x upsampler, distilled LoRA (rank 64) merged IN PLACE into the (fresh) stage-1 model for stage 2", dict(pipeline=PipelineType.DISTILLED, height=768, width=768, num_frames=65, stage1_steps=8, stage2_steps=3,
+                                                 distilled_loras=[(lora64, 0.8)], lora_in_place=True, fresh_model=True)),
 ]
 for name, kw in runs:
+    if kw.pop("fresh_model", False):          # an in-place merge consumes the model: these configs get their own copy of the base weights
+        del tr, Wt
+        torch.cuda.empty_cache()
+        Wt = LTXModel.random_weights(cfg, dev)
+        tr = LTXModel(cfg, Wt)
+        torch.cuda.synchronize()
     pj = f"/tmp/prof_{abs(hash(name))}.json"
     torch.cuda.reset_peak_memory_stats()
     torch.cuda.synchronize(); t0 = time.perf_counter()

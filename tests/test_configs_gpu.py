@@ -168,8 +168,16 @@ def test_two_stage_pipelines_match_oracle_at_768x768x65(dev, tmp_path, pipe):
         from mlx_video_amd.ltx_model import LTXModel
         own = {k: v.clone() for k, v in Wdev.items()}
         lat_ip = generate_video(pipeline=PipelineType.DISTILLED, images=[(img, 0, 1.0)], distilled_loras=[(str(lora_path), 0.8)],
-                                **dict(kw, noise_fn=_Noise(9, dev), transformer=LTXModel(mc, own), transformer_weights=own, stage2_lora_in_place=True))
+                                **dict(kw, noise_fn=_Noise(9, dev), transformer=LTXModel(mc, own), transformer_weights=own, lora_in_place=True))
         assert torch.equal(lat_ip, lat)
+    else:
+        # `loras` merged IN PLACE (one merged model serves both stages): bit-identical to the copy-building path
+        from mlx_video_amd.ltx_model import LTXModel
+        own = {k: v.clone() for k, v in Wdev.items()}
+        lat_ip = generate_video(pipeline=PipelineType.IC_LORA, images=[(img, 0, 1.0)], video_conditionings=[(vid, 0, 0.9)], loras=[(str(lora_path), 0.8)],
+                                **dict(kw, noise_fn=_Noise(9, dev), transformer=LTXModel(mc, own), transformer_weights=own, lora_in_place=True))
+        assert torch.equal(lat_ip, lat)
+    if pipe != "ic_lora":
         # the stage-2 LoRA must matter: the same run without it lands measurably elsewhere
         noise2 = _Noise(9, dev)
         kw2 = dict(kw, noise_fn=noise2)
